@@ -1,0 +1,260 @@
+/*
+ * omnivggt_hip.h -- C ABI of libomnivggt_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the OmniVGGT multi-view aggregator hot path
+ * (reference: omnivggt/models/omnivggt_aggregator.py:130-305,
+ * omnivggt/models/aggregator.py:312-341, omnivggt/layers/{block,attention,
+ * mlp,rope,patch_embed,vision_transformer}.py).  The reference has no FFI of
+ * its own (pure PyTorch); each entry below names the reference call site it
+ * replaces.  See INTEGRATION.md for the ctypes binding a maintainer would add.
+ *
+ * Conventions (all entries):
+ *   - `int fn(const <params>*, void* hip_stream)`; returns OVG_OK (0) or a
+ *     negative OVG_E_* code.  Never throws, never allocates or frees, never
+ *     synchronises the device.
+ *   - every pointer is a DEVICE pointer owned by the caller and must stay valid
+ *     until the stream reaches the call; 16-byte aligned unless noted.
+ *   - `dtype` selects the storage/MFMA input type of activations and weights:
+ *     OVG_BF16 / OVG_F16 (throughput modes, f32 accumulate) or OVG_F32
+ *     (parity mode, exact-f32 MFMA).  The residual stream, LayerNorm
+ *     statistics, softmax statistics, biases, LayerScale gammas, q/k-norm
+ *     affine parameters and the RoPE table are always f32.
+ *   - thread-safe for distinct streams; no global mutable state.
+ */
+#ifndef OMNIVGGT_HIP_H
+#define OMNIVGGT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OVG_ABI_VERSION 1
+
+enum { OVG_BF16 = 0, OVG_F16 = 1, OVG_F32 = 2 };
+
+enum {
+  OVG_OK = 0,
+  OVG_E_ARG = -1,      /* null pointer / bad shape / misalignment            */
+  OVG_E_DTYPE = -2,    /* unsupported dtype                                   */
+  OVG_E_LAUNCH = -3,   /* hipGetLastError() != hipSuccess after a launch      */
+  OVG_E_UNSUPPORTED = -4
+};
+
+/* Model constants of the path (omnivggt_aggregator.py:19-37). */
+#define OVG_C 1024      /* embed dim            */
+#define OVG_H 16        /* heads                */
+#define OVG_D 64        /* head dim             */
+#define OVG_HID 4096    /* MLP hidden           */
+#define OVG_KV_TILE 64  /* key tile: K/V^T buffers are padded to this */
+#define OVG_MAX_SEG 8   /* K/V segments per attention call (= ranks)  */
+
+int ovg_abi_version(void);
+/* human readable build string (static storage) */
+const char* ovg_build_info(void);
+
+/* ------------------------------------------------------------------ *
+ * LayerNorm over rows of 1024 (nn.LayerNorm: block.py:50,67 norm1/norm2,
+ * vision_transformer.py:264 final DINO norm).  x is the f32 residual
+ * stream with row stride ldx (elements); y is [rows,1024] in `dtype`
+ * (out_f32 != 0: y is f32 regardless of dtype).
+ * ------------------------------------------------------------------ */
+typedef struct {
+  const float* x; int64_t ldx;
+  void* y; int64_t ldy;
+  const float* weight; const float* bias;
+  int64_t rows; float eps; int dtype; int out_f32;
+} ovg_layernorm_params;
+int ovg_layernorm(const ovg_layernorm_params*, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Generic linear  Y = epilogue(X @ W^T + bias)   (nn.Linear / addmm).
+ * X [M,K] ld=ldx, W [N,K] ld=ldw, both `dtype`, K a multiple of 64.
+ * epilogue:
+ *   OVG_EPI_STORE : y[m,n] = acc + bias               (y dtype, or f32 if out_f32)
+ *   OVG_EPI_GELU  : y[m,n] = gelu_erf(acc + bias)     (mlp.py:35-36)
+ *   OVG_EPI_RES   : y_f32[m,n] = res_f32[m,n] + gamma[n]*(acc+bias)
+ *                   (+ inject[(m/inj_period),n] when m % inj_period == 0)
+ *                   (attention.py:75 + layer_scale.py:27 + block.py:105-106,
+ *                    omnivggt_aggregator.py:284-301 camera injection)
+ *   OVG_EPI_PATCH : y_f32[(m/p0)*p1 + off + m%p0, n] = acc + bias + table[(m%p0)+1, n]
+ *                   (patch_embed.py:75-77 + vision_transformer.py:220-224)
+ * ------------------------------------------------------------------ */
+enum { OVG_EPI_STORE = 0, OVG_EPI_GELU = 1, OVG_EPI_RES = 2, OVG_EPI_PATCH = 3 };
+typedef struct {
+  const void* x; int64_t ldx;
+  const void* w; int64_t ldw;
+  const float* bias;             /* [N] or NULL */
+  void* y; int64_t ldy;
+  int64_t M; int64_t N; int64_t K;
+  int dtype; int epilogue; int out_f32;
+  /* RES */
+  const float* res; int64_t ldres; const float* gamma;
+  const float* inject; int64_t inj_period;   /* inject may be NULL */
+  /* PATCH */
+  const float* table; int64_t p0; int64_t p1; int64_t row_off;
+} ovg_linear_params;
+int ovg_linear(const ovg_linear_params*, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Fused QKV projection (attention.py:52-58): qkv = X @ Wqkv^T + b, then per
+ * head LayerNorm(64) on q,k (if qk_norm), 2-D RoPE on q,k (if rope),
+ * q *= q_scale, and head-major stores:
+ *   q  [B*H, nq_pad, 64]     k [B*H, nk_pad, 64]     vt [B*H, 64, nk_pad]
+ * Row m of X is token n = m % seq of batch b = m / seq; RoPE positions are
+ * derived from t = m % tokens_per_view: t < 5 -> (0,0) else
+ * (1 + (t-5)/grid_w, 1 + (t-5)%grid_w)   (omnivggt_aggregator.py:215-224).
+ * rope_cos/rope_sin: f32 [max_pos,16] (rope.py:86-117, 16 unique freqs).
+ * Padding rows/cols of q,k,vt are never written (caller zero-fills once).
+ * ------------------------------------------------------------------ */
+typedef struct {
+  const void* x; int64_t ldx;       /* [M,1024] dtype */
+  const void* w;                    /* [3072,1024] dtype */
+  const float* bias;                /* [3072] */
+  void* q; void* k; void* vt;
+  int64_t M; int64_t seq; int64_t nq_pad; int64_t nk_pad;
+  int dtype;
+  int qk_norm; const float* qn_w; const float* qn_b; const float* kn_w; const float* kn_b; float qk_eps;
+  int rope; const float* rope_cos; const float* rope_sin; int max_pos;
+  int64_t tokens_per_view; int grid_w; int n_special;
+  float q_scale;
+} ovg_qkv_params;
+int ovg_qkv(const ovg_qkv_params*, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Flash attention forward, D=64, no mask, non-causal
+ * (F.scaled_dot_product_attention, attention.py:61-66).  q must already be
+ * multiplied by softmax_scale*log2(e) (ovg_qkv does it): the kernel uses
+ * exp2.  K/V^T arrive as `nseg` segments (1 on a single GPU; one per rank
+ * after the view-sharded all-gather) -- softmax runs across all of them.
+ *   q   [BH, nq_pad, 64]
+ *   seg[i].k [BH, nk_pad_i, 64], seg[i].vt [BH, 64, nk_pad_i], nk_i valid keys
+ *   out [B*nq, H*64] token-major (row = (bh/H)*nq + n, col = (bh%H)*64 + d), ld = ldo
+ * ------------------------------------------------------------------ */
+typedef struct { const void* k; const void* vt; int64_t nk; int64_t nk_pad; } ovg_kv_segment;
+typedef struct {
+  const void* q; int64_t nq; int64_t nq_pad;
+  ovg_kv_segment seg[OVG_MAX_SEG]; int nseg;
+  void* out; int64_t ldo;
+  int64_t BH; int dtype;
+  int variant;   /* 0 = default; >0 selects tuning variants */
+} ovg_attn_params;
+int ovg_flash_attn(const ovg_attn_params*, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * One pre-LN transformer block (block.py:81-107):
+ *   x = x + ls1 * proj(attn(qkv(norm1(x))));  x = x + ls2 * fc2(gelu(fc1(norm2(x))))
+ * run as LN -> QKV -> flash-attn -> proj(RES) -> LN -> fc1(GELU) -> fc2(RES [+inject]).
+ * x_in/x_out are f32 with row strides (x_out may alias x_in; they may also be
+ * the two halves of a (.., 2C) concat buffer, omnivggt_aggregator.py:250).
+ * ------------------------------------------------------------------ */
+typedef struct {
+  const void* n1_w; const void* n1_b;     /* f32 [1024] */
+  const void* qkv_w; const float* qkv_b;  /* dtype [3072,1024]; f32 [3072] */
+  const float* qn_w; const float* qn_b; const float* kn_w; const float* kn_b; /* f32 [64] or NULL */
+  const void* proj_w; const float* proj_b;
+  const float* ls1;                        /* f32 [1024] (ones if no LayerScale) */
+  const void* n2_w; const void* n2_b;
+  const void* fc1_w; const float* fc1_b;   /* dtype [4096,1024] */
+  const void* fc2_w; const float* fc2_b;   /* dtype [1024,4096] */
+  const float* ls2;
+} ovg_block_weights;
+
+typedef struct {
+  ovg_block_weights w;
+  const float* x_in; int64_t ld_in;
+  float* x_out; int64_t ld_out;
+  int64_t M;                 /* tokens processed by this rank            */
+  int64_t seq;               /* attention sequence length (per batch)     */
+  int64_t BH;                /* (M/seq) * 16                               */
+  int64_t nq_pad; int64_t nk_pad;
+  int dtype; float ln_eps; int qk_norm; int rope; float qk_eps;
+  const float* rope_cos; const float* rope_sin; int max_pos;
+  int64_t tokens_per_view; int grid_w; int n_special;
+  const float* inject; int64_t inj_period;     /* fc2 epilogue; NULL = none  */
+  /* caller-provided workspace */
+  void* ws_xn;    /* [M,1024] dtype */
+  void* ws_q; void* ws_k; void* ws_vt;
+  void* ws_attn;  /* [M,1024] dtype */
+  void* ws_hid;   /* [M,4096] dtype */
+  /* remote K/V segments (view-sharded global attention): when nseg_extra > 0 the
+   * attention step uses {local K/V^T} + extra[]; the caller fills `extra`
+   * between ovg_block_attn_prologue and ovg_block_attn_epilogue. */
+  ovg_kv_segment extra[OVG_MAX_SEG]; int nseg_extra; int local_seg_index;
+  int attn_variant;
+} ovg_block_params;
+/* whole block */
+int ovg_block_forward(const ovg_block_params*, void* stream);
+/* split form for the sharded path: prologue = LN1 + QKV (writes ws_q/k/vt);
+ * epilogue = attention (over local+extra segments) + proj + MLP. */
+int ovg_block_attn_prologue(const ovg_block_params*, void* stream);
+int ovg_block_attn_epilogue(const ovg_block_params*, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Patch im2col (Conv2d k=14,s=14 as a GEMM: patch_embed.py:65,75-77).
+ * img f32 [V,C,Hpx,Wpx]; out [V*gh*gw, k_pad] dtype, element k = c*196+ky*14+kx,
+ * zero for k >= C*196.  mode 0: (img[c]-mean[c])/std[c]  (omnivggt_aggregator.py:143)
+ * mode 1: depth/mask: c=0 -> depth/(mean_b+1e-8)*mask, c=1 -> mask
+ *         (omnivggt_aggregator.py:107-128,197); depth_stats = {sum,count} per batch
+ * ------------------------------------------------------------------ */
+typedef struct {
+  const float* img; const float* img2;   /* mode1: img=depth [V,H,W], img2=mask [V,H,W] */
+  void* out; int64_t k_pad;
+  int64_t V; int C; int Hpx; int Wpx; int dtype; int mode;
+  float mean[3]; float std[3];
+  const double* depth_stats;  /* mode1: [B][2] = {sum, count}; V = B*views_per_batch */
+  int64_t views_per_batch;
+} ovg_im2col_params;
+int ovg_im2col(const ovg_im2col_params*, void* stream);
+
+/* masked depth statistics (omnivggt_aggregator.py:118-123): stats[b] = {sum of
+ * depth where mask>0, count}.  partial: workspace of 2*nblocks doubles. */
+typedef struct {
+  const float* depth; const float* mask; int64_t B; int64_t n_per_batch;
+  double* stats; double* partial; int nblocks;
+} ovg_depth_stats_params;
+int ovg_depth_stats(const ovg_depth_stats_params*, void* stream);
+
+/* DINOv2 special rows (vision_transformer.py:220-224): x[v,0]=cls+pos[0], x[v,1..4]=reg */
+typedef struct {
+  float* x; int64_t ldx; int64_t V; int64_t tokens_per_view;
+  const float* cls; const float* pos0; const float* reg; int n_reg;
+} ovg_dino_specials_params;
+int ovg_dino_specials(const ovg_dino_specials_params*, void* stream);
+
+/* Token assembly before the AA trunk (omnivggt_aggregator.py:147-156,202-213 and
+ * vision_transformer.py:264-268): for each view v and token t
+ *   t == 0     : camera_token[slot] + cam_add[v]
+ *   1 <= t < 5 : register_token[slot][t-1]
+ *   t >= 5     : LayerNorm_eps(xd[v,t]) + (depth_row[v] >= 0 ? depth_tok[depth_row[v]*P0+t-5] : placeholder)
+ * slot = ((view0 + v) % S == 0) ? 0 : 1   (aggregator.py:343-366). */
+typedef struct {
+  const float* xd; int64_t ldxd;        /* DINO residual stream [V*P,1024] */
+  const float* norm_w; const float* norm_b; float eps;
+  const float* camera_token;            /* [2,1024] */
+  const float* register_token;          /* [2,4,1024] */
+  const float* cam_add;                 /* [V,1024] */
+  const float* depth_tok;               /* [Sd*P0,1024] or NULL */
+  const int32_t* depth_row;             /* [V] index into depth_tok views or -1 */
+  const float* placeholder;             /* [1024] */
+  float* out; int64_t ldo;
+  int64_t V; int64_t S; int64_t tokens_per_view; int n_special;
+  int64_t view0;                        /* global index of local view 0 (view-sharded ranks) */
+} ovg_assemble_params;
+int ovg_assemble_tokens(const ovg_assemble_params*, void* stream);
+
+/* strided f32 row copy/add helper: y[r, :n] = x[r, :n] (+ add[r / period, :n] on rows r%period==0) */
+typedef struct {
+  const float* x; int64_t ldx; float* y; int64_t ldy; int64_t rows; int64_t n;
+} ovg_copy_rows_params;
+int ovg_copy_rows(const ovg_copy_rows_params*, void* stream);
+
+/* MFMA lane-map probe (diagnostics; tools/selftest.py): fills out[64*4] with
+ * acc of one 16x16 MFMA for dtype given raw 16-byte A/B fragments per lane. */
+int ovg_probe_mfma(const void* a_frag, const void* b_frag, float* out, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

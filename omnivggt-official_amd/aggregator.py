@@ -1,0 +1,377 @@
+"""HIP-backed replacement of the reference's ZeroAggregator
+(omnivggt/models/omnivggt_aggregator.py:18-305, base omnivggt/models/aggregator.py:26-366).
+
+Same constructor keywords that matter for inference, same parameter names (state-dict keys),
+same forward signature and return value `(list[depth] of (B,S,P,2C) f32, patch_start_idx)`.
+All compute goes through libomnivggt_hip.so (ops.py / lib.py); there is no PyTorch fallback.
+
+Data layout in HBM (B=1 shown; DESIGN.md has the full table):
+  residual stream   f32, rows = tokens (view-major), lives INSIDE the output list: after
+                    frame block i it is out[i][..., :C], after global block i out[i][..., C:]
+                    (row stride 2C) -- the reference's torch.cat (omnivggt_aggregator.py:250)
+                    and the zero-padded injection add (:284-301) cost nothing here.
+  activations       compute dtype (bf16/f16/f32): LN output [T,C], attention output [T,C],
+                    MLP hidden [T,4C]
+  q,k               head-major [B'*16, N_pad, 64];  v transposed [B'*16, 64, N_pad]
+"""
+import ctypes as C_
+
+import torch
+import torch.nn as nn
+
+from . import camera_math
+from . import lib as L
+from . import ops
+
+C, HEADS, D = 1024, 16, 64
+RESNET_MEAN = (0.485, 0.456, 0.406)
+RESNET_STD = (0.229, 0.224, 0.225)
+
+
+# ----------------------------------------------------------------------------
+# parameter containers (names = reference state-dict keys; never called as modules)
+# ----------------------------------------------------------------------------
+class _Gamma(nn.Module):
+    def __init__(self, dim, init):
+        super().__init__()
+        self.gamma = nn.Parameter(init * torch.ones(dim))
+
+
+class _AttnParams(nn.Module):
+    def __init__(self, dim, qk_norm):
+        super().__init__()
+        self.qkv = nn.Linear(dim, 3 * dim)
+        self.proj = nn.Linear(dim, dim)
+        if qk_norm:
+            self.q_norm = nn.LayerNorm(dim // HEADS)
+            self.k_norm = nn.LayerNorm(dim // HEADS)
+
+
+class _MlpParams(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class BlockParamsModule(nn.Module):
+    """Parameters of one Block (layers/block.py:27-79)."""
+    def __init__(self, dim, qk_norm, ln_eps, ls_init):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=ln_eps)
+        self.attn = _AttnParams(dim, qk_norm)
+        self.ls1 = _Gamma(dim, ls_init)
+        self.norm2 = nn.LayerNorm(dim, eps=ln_eps)
+        self.mlp = _MlpParams(dim, 4 * dim)
+        self.ls2 = _Gamma(dim, ls_init)
+
+
+class _ConvProj(nn.Module):
+    def __init__(self, in_chans, dim):
+        super().__init__()
+        self.proj = nn.Conv2d(in_chans, dim, kernel_size=14, stride=14)
+
+
+class DinoParams(nn.Module):
+    """Parameters of the DINOv2 ViT-L/14-reg backbone (layers/vision_transformer.py:42-175)."""
+    def __init__(self, dim, depth, n_patches, n_reg):
+        super().__init__()
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, n_patches + 1, dim))
+        self.register_tokens = nn.Parameter(torch.zeros(1, n_reg, dim))
+        self.patch_embed = _ConvProj(3, dim)
+        self.blocks = nn.ModuleList([BlockParamsModule(dim, False, 1e-6, 1.0) for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+
+
+# ----------------------------------------------------------------------------
+# device-side runners
+# ----------------------------------------------------------------------------
+class Workspace:
+    """Scratch for one (tokens, sequence length) shape."""
+    def __init__(self, M, seq, dtype, device):
+        self.M, self.seq, self.dtype = M, seq, dtype
+        self.BH = (M // seq) * HEADS
+        self.xn = torch.empty(M, C, device=device, dtype=dtype)
+        self.attn = torch.empty(M, C, device=device, dtype=dtype)
+        self.hid = torch.empty(M, 4 * C, device=device, dtype=dtype)
+        self.q, self.k, self.vt = ops.alloc_qkv(self.BH, seq, seq, dtype, device)
+
+    def share_from(self, other):
+        """Reuse the LN / attention / hidden scratch of another workspace with the same M."""
+        self.xn, self.attn, self.hid = other.xn, other.attn, other.hid
+        return self
+
+
+class BlockRunner:
+    """Packed weights of one block + the ovg_block_forward call."""
+    _GEMM = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")
+
+    def __init__(self, sd, prefix, dtype, device, qk_norm, rope, ln_eps, rope_tables=None, attn_variant=0):
+        self.dtype, self.qk_norm, self.rope, self.ln_eps = dtype, qk_norm, rope, ln_eps
+        self.attn_variant = attn_variant
+        t = {}
+
+        def grab(name, dt):
+            t[name] = sd["%s.%s" % (prefix, name)].detach().to(device=device, dtype=dt).contiguous()
+            return L.ptr(t[name])
+
+        w = L.BlockWeights()
+        w.n1_w, w.n1_b = grab("norm1.weight", torch.float32), grab("norm1.bias", torch.float32)
+        w.qkv_w, w.qkv_b = grab("attn.qkv.weight", dtype), grab("attn.qkv.bias", torch.float32)
+        if qk_norm:
+            w.qn_w, w.qn_b = grab("attn.q_norm.weight", torch.float32), grab("attn.q_norm.bias", torch.float32)
+            w.kn_w, w.kn_b = grab("attn.k_norm.weight", torch.float32), grab("attn.k_norm.bias", torch.float32)
+        w.proj_w, w.proj_b = grab("attn.proj.weight", dtype), grab("attn.proj.bias", torch.float32)
+        w.ls1 = grab("ls1.gamma", torch.float32)
+        w.n2_w, w.n2_b = grab("norm2.weight", torch.float32), grab("norm2.bias", torch.float32)
+        w.fc1_w, w.fc1_b = grab("mlp.fc1.weight", dtype), grab("mlp.fc1.bias", torch.float32)
+        w.fc2_w, w.fc2_b = grab("mlp.fc2.weight", dtype), grab("mlp.fc2.bias", torch.float32)
+        w.ls2 = grab("ls2.gamma", torch.float32)
+        self.tensors, self.weights = t, w
+        if rope:
+            if rope_tables is None:
+                rope_tables = make_rope_tables(38, device)
+            self.rope_tables = rope_tables
+
+    def params(self, ws, x_in, x_out, inject=None, inj_period=0, tokens_per_view=1374, grid_w=37, n_special=5):
+        p = L.BlockParams()
+        p.w = self.weights
+        p.x_in, p.ld_in, p.x_out, p.ld_out = L.ptr(x_in), x_in.stride(0), L.ptr(x_out), x_out.stride(0)
+        p.M, p.seq, p.BH = ws.M, ws.seq, ws.BH
+        p.nq_pad, p.nk_pad = ws.q.shape[1], ws.k.shape[1]
+        p.dtype, p.ln_eps, p.qk_norm, p.rope, p.qk_eps = L.dtype_code(self.dtype), self.ln_eps, int(self.qk_norm), int(self.rope), 1e-5
+        if self.rope:
+            p.rope_cos, p.rope_sin, p.max_pos = L.ptr(self.rope_tables[0]), L.ptr(self.rope_tables[1]), self.rope_tables[0].shape[0]
+        p.tokens_per_view, p.grid_w, p.n_special = tokens_per_view, grid_w, n_special
+        if inject is not None:
+            p.inject, p.inj_period = L.ptr(inject), inj_period
+        p.ws_xn, p.ws_q, p.ws_k, p.ws_vt, p.ws_attn, p.ws_hid = (L.ptr(ws.xn), L.ptr(ws.q), L.ptr(ws.k), L.ptr(ws.vt),
+                                                                  L.ptr(ws.attn), L.ptr(ws.hid))
+        p.attn_variant = self.attn_variant
+        return p
+
+    def forward(self, ws, x_in, x_out, inject=None, inj_period=0, **kw):
+        """x_in/x_out: f32 [M,1024] row-strided views (x_out may alias x_in)."""
+        p = self.params(ws, x_in, x_out, inject, inj_period, **kw)
+        L.call("ovg_block_forward", p, torch.cuda.current_stream().cuda_stream)
+
+
+def make_rope_tables(max_pos, device, base=100.0, half_dim=32):
+    """cos/sin [max_pos,16] f32, computed exactly like layers/rope.py:86-117 (16 unique freqs)."""
+    exponents = torch.arange(0, half_dim, 2).float() / half_dim
+    inv_freq = 1.0 / (base ** exponents)
+    angles = torch.einsum("i,j->ij", torch.arange(max_pos, dtype=inv_freq.dtype), inv_freq)
+    return angles.cos().contiguous().to(device), angles.sin().contiguous().to(device)
+
+
+# ----------------------------------------------------------------------------
+class ZeroAggregator(nn.Module):
+    """Drop-in for omnivggt.models.omnivggt_aggregator.ZeroAggregator (inference only)."""
+
+    def __init__(self, img_size=518, patch_size=14, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4,
+                 num_register_tokens=4, pose_hidden_dim=512, patch_embed="dinov2_vitl14_reg", aa_order=("frame", "global"),
+                 aa_block_size=1, qk_norm=True, rope_freq=100, init_values=0.01, dino_depth=24,
+                 compute_dtype=torch.bfloat16, **unused):
+        super().__init__()
+        if embed_dim != C or num_heads != HEADS or patch_size != 14 or mlp_ratio != 4:
+            raise ValueError("the gfx950 kernels are built for embed_dim=1024, 16 heads, patch 14, mlp_ratio 4")
+        if patch_embed != "dinov2_vitl14_reg" or tuple(aa_order) != ("frame", "global") or aa_block_size != 1 or not qk_norm or rope_freq <= 0:
+            raise ValueError("unsupported aggregator configuration for the HIP path")
+        self.img_size, self.patch_size, self.depth, self.dino_depth = img_size, patch_size, depth, dino_depth
+        self.rope_freq = float(rope_freq)
+        self.patch_start_idx = 1 + num_register_tokens
+        self.aa_block_num = depth
+        grid = img_size // patch_size
+        self.grid, self.n_patches = grid, grid * grid
+        self.tokens_per_view = self.n_patches + self.patch_start_idx
+
+        self.patch_embed = DinoParams(embed_dim, dino_depth, self.n_patches, num_register_tokens)
+        self.frame_blocks = nn.ModuleList([BlockParamsModule(embed_dim, True, 1e-5, init_values) for _ in range(depth)])
+        self.global_blocks = nn.ModuleList([BlockParamsModule(embed_dim, True, 1e-5, init_values) for _ in range(depth)])
+        self.camera_token = nn.Parameter(torch.randn(1, 2, 1, embed_dim) * 1e-6)
+        self.register_token = nn.Parameter(torch.randn(1, 2, num_register_tokens, embed_dim) * 1e-6)
+        self.depth_placeholder = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pose_embeddings = nn.ModuleList([nn.Linear(pose_hidden_dim, embed_dim) for _ in range(depth + 1)])
+        self.camera_adapters = nn.ModuleList([nn.Linear(embed_dim, embed_dim) for _ in range(depth + 1)])
+        for a in self.camera_adapters:
+            nn.init.zeros_(a.weight)
+            nn.init.zeros_(a.bias)
+        self.depth_patch_embed = _ConvProj(2, embed_dim)
+        self.pose_hidden_dim = pose_hidden_dim
+        self.compute_dtype = compute_dtype
+        self.attn_variant = 0
+        self.shard = None           # set by sharding.ViewSharding for the multi-GPU path
+        self._packed = None
+        self._ws = {}
+        self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
+
+    # ------------------------------------------------------------------
+    def invalidate(self):
+        self._packed = None
+        self._ws = {}
+
+    def set_compute_dtype(self, dtype):
+        if dtype not in (torch.bfloat16, torch.float16, torch.float32):
+            raise ValueError("compute dtype must be bf16, f16 or f32")
+        if dtype != self.compute_dtype:
+            self.compute_dtype = dtype
+            self.invalidate()
+
+    def pack(self, device):
+        """One-time pre-pack after load_state_dict: GEMM weights -> compute dtype, the rest f32."""
+        if self._packed is not None and self._packed["device"] == device and self._packed["dtype"] == self.compute_dtype:
+            return self._packed
+        L.require_gpu()
+        dt = self.compute_dtype
+        sd = {k: v for k, v in self.state_dict().items()}
+        f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+        rope = make_rope_tables(self.grid + 1, device, self.rope_freq)
+        pk = {"device": device, "dtype": dt, "rope": rope}
+        pk["dino"] = [BlockRunner(sd, "patch_embed.blocks.%d" % i, dt, device, False, False, 1e-6, attn_variant=self.attn_variant)
+                      for i in range(self.dino_depth)]
+        pk["frame"] = [BlockRunner(sd, "frame_blocks.%d" % i, dt, device, True, True, 1e-5, rope, self.attn_variant) for i in range(self.depth)]
+        pk["global"] = [BlockRunner(sd, "global_blocks.%d" % i, dt, device, True, True, 1e-5, rope, self.attn_variant) for i in range(self.depth)]
+
+        def conv_as_gemm(w, k_pad):
+            w2 = w.detach().reshape(w.shape[0], -1)
+            out = torch.zeros(w.shape[0], k_pad, dtype=torch.float32)
+            out[:, : w2.shape[1]] = w2.float().cpu()
+            return out.to(device=device, dtype=dt).contiguous()
+
+        pk["patch_w"] = conv_as_gemm(sd["patch_embed.patch_embed.proj.weight"], 640)
+        pk["patch_b"] = f32(sd["patch_embed.patch_embed.proj.bias"])
+        pk["pos_embed"] = f32(sd["patch_embed.pos_embed"][0])                     # [1370,1024]
+        pk["cls"] = f32(sd["patch_embed.cls_token"].reshape(-1))
+        pk["reg"] = f32(sd["patch_embed.register_tokens"][0])                      # [4,1024]
+        pk["dino_norm_w"], pk["dino_norm_b"] = f32(sd["patch_embed.norm.weight"]), f32(sd["patch_embed.norm.bias"])
+        pk["depth_w"] = conv_as_gemm(sd["depth_patch_embed.proj.weight"], 448)
+        pk["depth_b"] = f32(sd["depth_patch_embed.proj.bias"])
+        pk["camera_token"] = f32(sd["camera_token"].reshape(2, C))
+        pk["register_token"] = f32(sd["register_token"].reshape(2, -1, C))
+        pk["placeholder"] = f32(sd["depth_placeholder"].reshape(-1))
+        # camera modality tables (exact f32 MFMA path): all pose embeddings stacked into one GEMM
+        G = self.depth + 1
+        pe_w = torch.zeros(G * C, 64)
+        for i in range(G):
+            pe_w[i * C:(i + 1) * C, : self.pose_hidden_dim] = sd["pose_embeddings.%d.weight" % i].float().cpu()
+        pk["pose_w"] = pe_w.to(device)
+        pk["pose_b"] = torch.cat([sd["pose_embeddings.%d.bias" % i].float().cpu() for i in range(G)]).to(device)
+        pk["adapt_w"] = [f32(sd["camera_adapters.%d.weight" % i]) for i in range(G)]
+        pk["adapt_b"] = [f32(sd["camera_adapters.%d.bias" % i]) for i in range(G)]
+        self._packed = pk
+        return pk
+
+    def workspace(self, M, seq, device):
+        key = (M, seq, self.compute_dtype, str(device))
+        if key not in self._ws:
+            ws = Workspace(M, seq, self.compute_dtype, device)
+            for (m2, _, dt2, dv2), other in self._ws.items():
+                if m2 == M and dt2 == self.compute_dtype and dv2 == str(device):
+                    ws.share_from(other)
+                    break
+            self._ws[key] = ws
+        return self._ws[key]
+
+    # ------------------------------------------------------------------
+    def camera_tables(self, pk, extrinsics, intrinsics, camera_gt_index, B, S, hw, device):
+        """[depth+1] list of f32 [B*S,1024]: camera_adapters[i](scatter(pose_embeddings[i](enc)))
+        (omnivggt_aggregator.py:158-182,211,273-287).  Views without a GT camera get the
+        adapter bias (Linear of a zero row)."""
+        K = B * S
+        G = self.depth + 1
+        if len(camera_gt_index) == 0:
+            return [b.unsqueeze(0).expand(K, C).contiguous() for b in pk["adapt_b"]]
+        idx = torch.tensor(list(camera_gt_index))
+        ext = torch.index_select(extrinsics.detach().float().cpu(), 1, idx)
+        intr = torch.index_select(intrinsics.detach().float().cpu(), 1, idx)
+        enc = camera_math.pose_encoding(camera_math.normalize_extrinsics(ext), intr, hw)      # [B,Sc,9]
+        Sc = len(camera_gt_index)
+        x = torch.zeros(B * Sc, 64)
+        x[:, : self.pose_hidden_dim] = enc.reshape(B * Sc, -1)
+        emb = ops.linear(x.to(device), pk["pose_w"], pk["pose_b"], torch.float32, out_f32=True)   # [B*Sc, G*1024]
+        rows = (torch.arange(B).unsqueeze(1) * S + idx.unsqueeze(0)).reshape(-1).to(device)
+        tables = []
+        for i in range(G):
+            full = torch.zeros(K, C, device=device)
+            full[rows] = emb[:, i * C:(i + 1) * C]
+            tables.append(ops.linear(full, pk["adapt_w"][i], pk["adapt_b"][i], torch.float32, out_f32=True))
+        return tables
+
+    def depth_tokens(self, pk, depth, mask, depth_gt_index, B, S, device):
+        """(depth_tok [B*n*P0,1024] f32 or None, depth_row int32 [B*S])
+        (omnivggt_aggregator.py:107-128,185-208)."""
+        K = B * S
+        row = torch.full((K,), -1, dtype=torch.int32)
+        n = len(depth_gt_index)
+        if n == 0:
+            return None, row.to(device)
+        if tuple(depth.shape[:4]) != tuple(mask.shape):
+            raise AssertionError("mask and depth must have the same first four dimensions")
+        idx = torch.tensor(list(depth_gt_index), device=device)
+        H, W = depth.shape[2], depth.shape[3]
+        d_sel = torch.index_select(depth.to(device).float(), 1, idx).reshape(B, n * H * W).contiguous()
+        m_sel = torch.index_select(mask.to(device).float(), 1, idx).reshape(B, n * H * W).contiguous()
+        stats = ops.depth_stats(d_sel, m_sel)
+        cols = ops.im2col_depth(d_sel.view(B * n, H, W), m_sel.view(B * n, H, W), stats, n, self.compute_dtype)
+        tok = ops.linear(cols, pk["depth_w"], pk["depth_b"], self.compute_dtype, out_f32=True)
+        for b in range(B):
+            for j, s in enumerate(depth_gt_index):
+                row[b * S + s] = b * n + j
+        return tok, row.to(device)
+
+    # ------------------------------------------------------------------
+    def embed(self, pk, images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index, view_slice=None):
+        """DINO backbone + modality fusion -> (tokens0 f32 [K*P,1024], camera tables).
+        view_slice=(lo,hi) restricts the per-view work to a contiguous range of the B*S views
+        (multi-GPU: each rank embeds its own views; global statistics still span all views)."""
+        B, S, C_in, H, W = images.shape
+        device = images.device
+        P = self.tokens_per_view
+        K = B * S
+        lo, hi = (0, K) if view_slice is None else view_slice
+        Kl = hi - lo
+        dt = self.compute_dtype
+        imgs = images.reshape(K, C_in, H, W)[lo:hi].float().contiguous()
+        cols = ops.im2col_rgb(imgs, dt, mean=RESNET_MEAN, std=RESNET_STD)
+        xd = torch.empty(Kl * P, C, device=device, dtype=torch.float32)
+        ops.linear(cols, pk["patch_w"], pk["patch_b"], dt, epilogue=L.EPI_PATCH, out=xd, table=pk["pos_embed"],
+                   p0=self.n_patches, p1=P, row_off=self.patch_start_idx)
+        ops.dino_specials(xd, Kl, P, pk["cls"], pk["pos_embed"][0], pk["reg"])
+        ws = self.workspace(Kl * P, P, device)
+        for blk in pk["dino"]:
+            blk.forward(ws, xd, xd)
+        tables = self.camera_tables(pk, extrinsics, intrinsics, camera_gt_index, B, S, (H, W), device)
+        dtok, drow = self.depth_tokens(pk, depth, mask, depth_gt_index, B, S, device)
+        tokens0 = torch.empty(Kl * P, C, device=device, dtype=torch.float32)
+        ops.assemble_tokens(xd, pk["dino_norm_w"], pk["dino_norm_b"], 1e-6, pk["camera_token"], pk["register_token"],
+                            tables[0][lo:hi].contiguous(), dtok, drow[lo:hi].contiguous(), pk["placeholder"], tokens0, Kl, S,
+                            P, self.patch_start_idx, view0=lo)
+        return tokens0, tables
+
+    def forward(self, images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index):
+        B, S, C_in, H, W = images.shape
+        if C_in != 3:
+            raise ValueError(f"Expected 3 input channels, got {C_in}")
+        if H != self.img_size or W != self.img_size:
+            raise NotImplementedError("the HIP path handles %dx%d inputs (pos-embed interpolation is a 'next' row)" % (self.img_size, self.img_size))
+        if not images.is_cuda:
+            raise L.OvgError("ZeroAggregator.forward needs HIP device tensors: there is no CPU fallback")
+        if self.shard is not None:
+            return self.shard.forward(self, images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index)
+        device = images.device
+        pk = self.pack(device)
+        P, K = self.tokens_per_view, B * S
+        T = K * P
+        with torch.no_grad():
+            tokens0, tables = self.embed(pk, images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index)
+            ws_f = self.workspace(T, P, device)
+            ws_g = self.workspace(T, S * P, device)
+            outs = [torch.empty(B, S, P, 2 * C, device=device, dtype=torch.float32) for _ in range(self.depth)]
+            x = tokens0
+            for i in range(self.depth):
+                buf = outs[i].view(T, 2 * C)
+                pk["frame"][i].forward(ws_f, x, buf[:, :C], inject=tables[i + 1], inj_period=P)
+                pk["global"][i].forward(ws_g, buf[:, :C], buf[:, C:])
+                x = buf[:, C:]
+        return outs, self.patch_start_idx

@@ -1,0 +1,284 @@
+// Flash attention forward for the aggregator (gfx950), head_dim 64, no mask.
+// Replaces F.scaled_dot_product_attention at omnivggt/layers/attention.py:61-66 for the
+// frame-local blocks (batch = views*16 heads, N = 1374) and the global cross-view blocks
+// (batch = 16 heads, N = S*1374; omnivggt/models/aggregator.py:317-336).
+//
+// Formulation (all on 16x16 MFMA tiles, "swapped" so softmax rows are lane-local):
+//   S^T[key,q] = K[key,:] . Q[q,:]          A = K rows (LDS),  B = Q rows (registers)
+//   O^T[d,q]  += V^T[d,key] * P^T[key,q]    A = V^T rows (LDS), B = P (registers, from S^T)
+// A lane (q = lane&15, g = lane>>4) holds S^T for keys 16*kt + 4g + r: one q row lives in
+// the 4 lanes {q, q+16, q+32, q+48}, so the row max/sum need two xor-shuffles only, the
+// running max/sum/alpha are lane-local, and P feeds the PV MFMA with NO cross-lane
+// movement: the k-slot -> key assignment of the P fragment is simply mirrored by the
+// V^T fragment gather (two 8-byte LDS reads per fragment for 16-bit types).
+// V arrives pre-transposed (V^T [BH,64,nk_pad], written by the QKV epilogue), K/V^T tiles
+// are register-staged into double-buffered LDS (issue-early / write-late), the K tile is
+// XOR-swizzled and the V^T tile row-padded so every fragment read is conflict free.
+// q is pre-scaled by softmax_scale*log2(e): probabilities are exp2(s - m).
+// K/V^T may come as several segments (one per rank of the view-sharded all-gather).
+#include "ovg_common.h"
+
+namespace {
+
+constexpr int BC = OVG_KV_TILE;   // keys per tile
+
+template <typename T> struct VFrag;
+// 16-bit types: 32 keys per PV step u; slot j -> key 32u + 16*(j>>2) + 4g + (j&3)
+template <typename T> struct VFrag {
+  static constexpr int kSteps = 2;
+  static constexpr int kRow = 136;   // V^T LDS row stride (128 B + 8 B pad): b64 reads conflict free
+  static OVG_DEV u32x4 load(const unsigned char* vl, int d, int step, int g) {
+    const unsigned char* p = vl + d * kRow + (32 * step + 4 * g) * 2;
+    const u32x2 lo = *reinterpret_cast<const u32x2*>(p);
+    const u32x2 hi = *reinterpret_cast<const u32x2*>(p + 32);
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+  }
+  static OVG_DEV u32x4 pfrag(const f32x4 (&s)[4], int step) {
+    T v[8];
+    const f32x4 a = s[2 * step], b = s[2 * step + 1];
+    v[0] = TT<T>::from_f32(a[0]); v[1] = TT<T>::from_f32(a[1]); v[2] = TT<T>::from_f32(a[2]); v[3] = TT<T>::from_f32(a[3]);
+    v[4] = TT<T>::from_f32(b[0]); v[5] = TT<T>::from_f32(b[1]); v[6] = TT<T>::from_f32(b[2]); v[7] = TT<T>::from_f32(b[3]);
+    u32x4 r;
+    __builtin_memcpy(&r, v, 16);
+    return r;
+  }
+};
+// f32: 16 keys per PV step kt; MFMA i uses key 16kt + 4g + i
+template <> struct VFrag<float> {
+  static constexpr int kSteps = 4;
+  static constexpr int kRow = 272;
+  static OVG_DEV u32x4 load(const unsigned char* vl, int d, int step, int g) {
+    return *reinterpret_cast<const u32x4*>(vl + d * kRow + (16 * step + 4 * g) * 4);
+  }
+  static OVG_DEV u32x4 pfrag(const f32x4 (&s)[4], int step) { return __builtin_bit_cast(u32x4, s[step]); }
+};
+
+// QB = 16-row q blocks per wave; 4 waves -> BQ = 64*QB q rows per workgroup
+template <typename T, int QB>
+__global__ __launch_bounds__(256) void attn_kernel(ovg_attn_params p, int nqt, int total_tiles) {
+  constexpr int RB = OVG_D * (int)sizeof(T);   // K row bytes
+  constexpr int NCH = RB / 16;                 // 16 B chunks per K row
+  constexpr int NKK = NCH / 4;                 // MFMA steps over d
+  constexpr int VROW = VFrag<T>::kRow;
+  constexpr int NSTEP = VFrag<T>::kSteps;
+  constexpr int KT_B = BC * RB, VT_B = OVG_D * VROW;
+  constexpr int NBUF = sizeof(T) == 2 ? 2 : 1;
+  constexpr int CPT = BC * NCH / 256;          // chunks per thread per tile (2 or 4)
+  constexpr int BQ = 64 * QB;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NBUF * (KT_B + VT_B)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, lr = lane & 15;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = lid / nqt, qt = lid % nqt;
+  const int nq = (int)p.nq;
+  const int q0 = qt * BQ + wave * 16 * QB;
+
+  // ---- Q fragments (B operand), straight from global -------------------
+  u32x4 qf[QB][NKK];
+  {
+    const unsigned char* qbase = static_cast<const unsigned char*>(p.q) + (int64_t)bh * p.nq_pad * RB;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      int q = q0 + qb * 16 + lr; q = q < nq ? q : nq - 1;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk)
+        qf[qb][kk] = *reinterpret_cast<const u32x4*>(qbase + (int64_t)q * RB + (4 * kk + g) * 16);
+    }
+  }
+
+  f32x4 o[QB][4];
+  float mrow[QB], lrow[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    mrow[qb] = -1.0e30f; lrow[qb] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[qb][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // ---- staging state: (segment, tile) of the NEXT tile to fetch ---------
+  int fseg = 0, ftile = 0;
+  int f_ntiles = (int)((p.seg[0].nk + BC - 1) / BC);
+  u32x4 rk[CPT], rv[CPT];
+  int k_goff[CPT], v_row[CPT], v_ch[CPT], k_loff[CPT], v_loff[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = tid + 256 * i;
+    const int row = c / NCH, ch = c % NCH;
+    k_goff[i] = c * 16;
+    k_loff[i] = swz_off<RB>(row, ch);
+    v_row[i] = row; v_ch[i] = ch;
+    v_loff[i] = row * VROW + ch * 16;
+  }
+  auto fetch = [&]() {
+    const ovg_kv_segment sg = p.seg[fseg];
+    const unsigned char* kb = static_cast<const unsigned char*>(sg.k) + ((int64_t)bh * sg.nk_pad + (int64_t)ftile * BC) * RB;
+    const unsigned char* vb = static_cast<const unsigned char*>(sg.vt) + ((int64_t)bh * OVG_D * sg.nk_pad + (int64_t)ftile * BC) * (int64_t)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      rk[i] = *reinterpret_cast<const u32x4*>(kb + k_goff[i]);
+      rv[i] = *reinterpret_cast<const u32x4*>(vb + (int64_t)v_row[i] * sg.nk_pad * (int64_t)sizeof(T) + v_ch[i] * 16);
+    }
+    if (++ftile == f_ntiles) {
+      ftile = 0; ++fseg;
+      if (fseg < p.nseg) f_ntiles = (int)((p.seg[fseg].nk + BC - 1) / BC);
+    }
+  };
+  auto stash = [&](int buf) {
+    unsigned char* kl = lds + buf * (KT_B + VT_B);
+    unsigned char* vl = kl + KT_B;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      *reinterpret_cast<u32x4*>(kl + k_loff[i]) = rk[i];
+      *reinterpret_cast<u32x2*>(vl + v_loff[i]) = u32x2{rv[i][0], rv[i][1]};
+      *reinterpret_cast<u32x2*>(vl + v_loff[i] + 8) = u32x2{rv[i][2], rv[i][3]};
+    }
+  };
+
+  // compute-side bookkeeping: valid keys left in the current segment
+  int cseg = 0, ctile = 0;
+  int c_ntiles = f_ntiles;
+  int c_nk = (int)p.seg[0].nk;
+
+  fetch();
+  stash(0);
+  __syncthreads();
+
+  int buf = 0;
+  for (int j = 0; j < total_tiles; ++j) {
+    const bool more = (j + 1) < total_tiles;
+    if (more) fetch();
+
+    const unsigned char* kl = lds + buf * (KT_B + VT_B);
+    const unsigned char* vl = kl + KT_B;
+
+    // ---- S^T = K Q^T ----------------------------------------------------
+    f32x4 s[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) s[qb][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        const u32x4 kf = *reinterpret_cast<const u32x4*>(kl + swz_off<RB>(16 * kt + lr, 4 * kk + g));
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) TT<T>::mma(s[qb][kt], kf, qf[qb][kk]);
+      }
+    }
+    // ---- mask the ragged tail of a segment ------------------------------
+    const int kv0 = ctile * BC;
+    if (kv0 + BC > c_nk) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool dead = (kv0 + 16 * kt + 4 * g + r) >= c_nk;
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) s[qb][kt][r] = dead ? -INFINITY : s[qb][kt][r];
+        }
+    }
+    // ---- online softmax (per q block) -----------------------------------
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float mx = s[qb][0][0];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qb][kt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mrow[qb], mx);
+      const float alpha = __builtin_amdgcn_exp2f(mrow[qb] - mnew);
+      mrow[qb] = mnew;
+      float rs = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(s[qb][kt][r] - mnew);
+          s[qb][kt][r] = pv;
+          rs += pv;
+        }
+      lrow[qb] = lrow[qb] * alpha + rs;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[qb][dt] *= alpha;
+    }
+    // ---- O^T += V^T P^T --------------------------------------------------
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+      u32x4 pf[QB];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) pf[qb] = VFrag<T>::pfrag(s[qb], st);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const u32x4 vf = VFrag<T>::load(vl, 16 * dt + lr, st, g);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) TT<T>::mma(o[qb][dt], vf, pf[qb]);
+      }
+    }
+
+    // advance compute-side tile bookkeeping
+    if (++ctile == c_ntiles) {
+      ctile = 0; ++cseg;
+      if (cseg < p.nseg) { c_nk = (int)p.seg[cseg].nk; c_ntiles = (c_nk + BC - 1) / BC; }
+    }
+    if (NBUF == 1) __syncthreads();
+    if (more) stash(NBUF == 2 ? (buf ^ 1) : 0);
+    __syncthreads();
+    if (NBUF == 2) buf ^= 1;
+  }
+
+  // ---- epilogue: normalise and store token-major ---------------------------
+  const int bq = bh / OVG_H, hh = bh % OVG_H;
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    float lt = lrow[qb];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    const float inv = 1.0f / lt;
+    const int q = q0 + qb * 16 + lr;
+    if (q < nq) {
+      T* dst = static_cast<T*>(p.out) + ((int64_t)bq * nq + q) * p.ldo + hh * OVG_D + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        store4<T>(dst + 16 * dt, o[qb][dt][0] * inv, o[qb][dt][1] * inv, o[qb][dt][2] * inv, o[qb][dt][3] * inv);
+    }
+  }
+}
+
+template <typename T, int QB>
+int launch_attn(const ovg_attn_params& p, hipStream_t st) {
+  constexpr int BQ = 64 * QB;
+  const int nqt = (int)((p.nq + BQ - 1) / BQ);
+  int total = 0;
+  for (int i = 0; i < p.nseg; ++i) total += (int)((p.seg[i].nk + BC - 1) / BC);
+  const dim3 grid((unsigned)(p.BH * nqt)), block(256);
+  hipLaunchKernelGGL((attn_kernel<T, QB>), grid, block, 0, st, p, nqt, total);
+  OVG_CHECK_LAUNCH();
+  return OVG_OK;
+}
+
+}  // namespace
+
+extern "C" int ovg_flash_attn(const ovg_attn_params* p, void* stream) {
+  if (!p || !p->q || !p->out) return OVG_E_ARG;
+  if (p->nq <= 0 || p->nq_pad < p->nq || p->BH <= 0 || p->nseg < 1 || p->nseg > OVG_MAX_SEG) return OVG_E_ARG;
+  if (p->BH * ((p->nq + 63) / 64) > (int64_t)1 << 30) return OVG_E_ARG;
+  for (int i = 0; i < p->nseg; ++i) {
+    const ovg_kv_segment& s = p->seg[i];
+    if (!s.k || !s.vt || s.nk <= 0 || s.nk_pad % BC != 0 || s.nk_pad < ((s.nk + BC - 1) / BC) * BC) return OVG_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(s.k) | reinterpret_cast<uintptr_t>(s.vt)) & 15) return OVG_E_ARG;
+  }
+  if ((reinterpret_cast<uintptr_t>(p->q) | reinterpret_cast<uintptr_t>(p->out)) & 15) return OVG_E_ARG;
+  if (p->ldo % 4) return OVG_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool big = p->variant == 2 || (p->variant == 0 && p->nq >= 4096);
+  switch (p->dtype) {
+    case OVG_BF16: return big ? launch_attn<bf16_t, 2>(*p, st) : launch_attn<bf16_t, 1>(*p, st);
+    case OVG_F16: return big ? launch_attn<f16_t, 2>(*p, st) : launch_attn<f16_t, 1>(*p, st);
+    case OVG_F32: return launch_attn<float, 1>(*p, st);
+    default: return OVG_E_DTYPE;
+  }
+}

@@ -1,0 +1,98 @@
+// Device-side helpers shared by the gfx950 kernels of libomnivggt_hip.so.
+// CDNA4 only: wave64, MFMA 16x16 tiles, 16-byte operand fragments.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/omnivggt_hip.h"
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(8 * sizeof(_Float16)))) _Float16 f16x8;
+
+#define OVG_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------
+// Type traits.  A "fragment" is 16 raw bytes per lane: 8 bf16/f16 (one
+// 16x16x32 MFMA) or 4 f32 (four 16x16x4 MFMAs).  Lane l supplies row (l&15)
+// of its operand and the 16-byte chunk (4*kk + (l>>4)) of that row; because A
+// and B use the same chunk->k assignment the contraction is exact for any
+// hardware k ordering inside the chunk.
+// ---------------------------------------------------------------------------
+template <typename T> struct TT;
+template <> struct TT<bf16_t> {
+  static constexpr int kDtype = OVG_BF16;
+  static constexpr int kPerChunk = 8;  // elements per 16 B
+  static OVG_DEV void mma(f32x4& c, const u32x4& a, const u32x4& b) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+  static OVG_DEV bf16_t from_f32(float f) { return static_cast<bf16_t>(f); }
+  static OVG_DEV float to_f32(bf16_t v) { return static_cast<float>(v); }
+};
+template <> struct TT<f16_t> {
+  static constexpr int kDtype = OVG_F16;
+  static constexpr int kPerChunk = 8;
+  static OVG_DEV void mma(f32x4& c, const u32x4& a, const u32x4& b) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+  static OVG_DEV f16_t from_f32(float f) { return static_cast<f16_t>(f); }
+  static OVG_DEV float to_f32(f16_t v) { return static_cast<float>(v); }
+};
+template <> struct TT<float> {
+  static constexpr int kDtype = OVG_F32;
+  static constexpr int kPerChunk = 4;
+  static OVG_DEV void mma(f32x4& c, const u32x4& a, const u32x4& b) {
+    f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], c, 0, 0, 0);
+  }
+  static OVG_DEV float from_f32(float f) { return f; }
+  static OVG_DEV float to_f32(float v) { return v; }
+};
+
+// pack 4 f32 -> 4 T (8 B for 16-bit types, 16 B for f32) and store
+template <typename T> OVG_DEV void store4(T* dst, float a, float b, float c, float d);
+template <> OVG_DEV void store4<float>(float* dst, float a, float b, float c, float d) {
+  f32x4 v = {a, b, c, d};
+  *reinterpret_cast<f32x4*>(dst) = v;
+}
+template <> OVG_DEV void store4<bf16_t>(bf16_t* dst, float a, float b, float c, float d) {
+  typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+  bf16x4 v = {static_cast<bf16_t>(a), static_cast<bf16_t>(b), static_cast<bf16_t>(c), static_cast<bf16_t>(d)};
+  *reinterpret_cast<bf16x4*>(dst) = v;
+}
+template <> OVG_DEV void store4<f16_t>(f16_t* dst, float a, float b, float c, float d) {
+  typedef __attribute__((__vector_size__(4 * sizeof(_Float16)))) _Float16 f16x4;
+  f16x4 v = {static_cast<f16_t>(a), static_cast<f16_t>(b), static_cast<f16_t>(c), static_cast<f16_t>(d)};
+  *reinterpret_cast<f16x4*>(dst) = v;
+}
+
+// LDS tile of rows of RB bytes (RB = 128 or 256), 16-byte chunks XOR-swizzled so
+// that ds_read_b128 of {16 rows x one chunk column} is bank-conflict free:
+//   128 B rows: chunk ^= (row>>1)&7   (two rows share one 256 B bank row)
+//   256 B rows: chunk ^= row&15
+template <int RB> OVG_DEV int swz_off(int row, int chunk) {
+  if constexpr (RB == 128) return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+  else return row * 256 + ((chunk ^ (row & 15)) << 4);
+}
+
+OVG_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// XCD-aware 1-D block remap (8 XCDs, block b runs on XCD b%8 -- speed only):
+// consecutive logical ids share an XCD/L2.  Bijective for any n.
+OVG_DEV int xcd_remap(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+#define OVG_CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return OVG_E_LAUNCH; } while (0)

@@ -1,0 +1,172 @@
+"""ctypes binding of libomnivggt_hip.so (the C ABI declared in include/omnivggt_hip.h).
+
+This is the ONLY way the Python host reaches compute: there is no eager/PyTorch
+fallback.  Importing this module never needs a GPU (the library loads on a CPU-only
+host so the symbol table can be checked); calling a kernel without one fails loudly.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libomnivggt_hip.so")
+
+OVG_BF16, OVG_F16, OVG_F32 = 0, 1, 2
+EPI_STORE, EPI_GELU, EPI_RES, EPI_PATCH = 0, 1, 2, 3
+OVG_MAX_SEG = 8
+KV_TILE = 64
+ABI_VERSION = 1
+
+ERRORS = {0: "OVG_OK", -1: "OVG_E_ARG", -2: "OVG_E_DTYPE", -3: "OVG_E_LAUNCH", -4: "OVG_E_UNSUPPORTED"}
+
+vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+
+
+class LayerNormParams(C.Structure):
+    _fields_ = [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("weight", vp), ("bias", vp),
+                ("rows", i64), ("eps", f32), ("dtype", i32), ("out_f32", i32)]
+
+
+class LinearParams(C.Structure):
+    _fields_ = [("x", vp), ("ldx", i64), ("w", vp), ("ldw", i64), ("bias", vp), ("y", vp), ("ldy", i64),
+                ("M", i64), ("N", i64), ("K", i64), ("dtype", i32), ("epilogue", i32), ("out_f32", i32),
+                ("res", vp), ("ldres", i64), ("gamma", vp), ("inject", vp), ("inj_period", i64),
+                ("table", vp), ("p0", i64), ("p1", i64), ("row_off", i64)]
+
+
+class QkvParams(C.Structure):
+    _fields_ = [("x", vp), ("ldx", i64), ("w", vp), ("bias", vp), ("q", vp), ("k", vp), ("vt", vp),
+                ("M", i64), ("seq", i64), ("nq_pad", i64), ("nk_pad", i64), ("dtype", i32),
+                ("qk_norm", i32), ("qn_w", vp), ("qn_b", vp), ("kn_w", vp), ("kn_b", vp), ("qk_eps", f32),
+                ("rope", i32), ("rope_cos", vp), ("rope_sin", vp), ("max_pos", i32),
+                ("tokens_per_view", i64), ("grid_w", i32), ("n_special", i32), ("q_scale", f32)]
+
+
+class KvSegment(C.Structure):
+    _fields_ = [("k", vp), ("vt", vp), ("nk", i64), ("nk_pad", i64)]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [("q", vp), ("nq", i64), ("nq_pad", i64), ("seg", KvSegment * OVG_MAX_SEG), ("nseg", i32),
+                ("out", vp), ("ldo", i64), ("BH", i64), ("dtype", i32), ("variant", i32)]
+
+
+class BlockWeights(C.Structure):
+    _fields_ = [("n1_w", vp), ("n1_b", vp), ("qkv_w", vp), ("qkv_b", vp),
+                ("qn_w", vp), ("qn_b", vp), ("kn_w", vp), ("kn_b", vp),
+                ("proj_w", vp), ("proj_b", vp), ("ls1", vp), ("n2_w", vp), ("n2_b", vp),
+                ("fc1_w", vp), ("fc1_b", vp), ("fc2_w", vp), ("fc2_b", vp), ("ls2", vp)]
+
+
+class BlockParams(C.Structure):
+    _fields_ = [("w", BlockWeights), ("x_in", vp), ("ld_in", i64), ("x_out", vp), ("ld_out", i64),
+                ("M", i64), ("seq", i64), ("BH", i64), ("nq_pad", i64), ("nk_pad", i64),
+                ("dtype", i32), ("ln_eps", f32), ("qk_norm", i32), ("rope", i32), ("qk_eps", f32),
+                ("rope_cos", vp), ("rope_sin", vp), ("max_pos", i32),
+                ("tokens_per_view", i64), ("grid_w", i32), ("n_special", i32),
+                ("inject", vp), ("inj_period", i64),
+                ("ws_xn", vp), ("ws_q", vp), ("ws_k", vp), ("ws_vt", vp), ("ws_attn", vp), ("ws_hid", vp),
+                ("extra", KvSegment * OVG_MAX_SEG), ("nseg_extra", i32), ("local_seg_index", i32),
+                ("attn_variant", i32)]
+
+
+class Im2colParams(C.Structure):
+    _fields_ = [("img", vp), ("img2", vp), ("out", vp), ("k_pad", i64), ("V", i64), ("C", i32), ("Hpx", i32),
+                ("Wpx", i32), ("dtype", i32), ("mode", i32), ("mean", f32 * 3), ("std", f32 * 3),
+                ("depth_stats", vp), ("views_per_batch", i64)]
+
+
+class DepthStatsParams(C.Structure):
+    _fields_ = [("depth", vp), ("mask", vp), ("B", i64), ("n_per_batch", i64), ("stats", vp), ("partial", vp),
+                ("nblocks", i32)]
+
+
+class DinoSpecialsParams(C.Structure):
+    _fields_ = [("x", vp), ("ldx", i64), ("V", i64), ("tokens_per_view", i64), ("cls", vp), ("pos0", vp),
+                ("reg", vp), ("n_reg", i32)]
+
+
+class AssembleParams(C.Structure):
+    _fields_ = [("xd", vp), ("ldxd", i64), ("norm_w", vp), ("norm_b", vp), ("eps", f32),
+                ("camera_token", vp), ("register_token", vp), ("cam_add", vp), ("depth_tok", vp),
+                ("depth_row", vp), ("placeholder", vp), ("out", vp), ("ldo", i64),
+                ("V", i64), ("S", i64), ("tokens_per_view", i64), ("n_special", i32), ("view0", i64)]
+
+
+class CopyRowsParams(C.Structure):
+    _fields_ = [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("n", i64)]
+
+
+# every entry point of include/omnivggt_hip.h: name -> (restype, argtypes)
+SYMBOLS = {
+    "ovg_abi_version": (i32, []),
+    "ovg_build_info": (C.c_char_p, []),
+    "ovg_layernorm": (i32, [C.POINTER(LayerNormParams), vp]),
+    "ovg_linear": (i32, [C.POINTER(LinearParams), vp]),
+    "ovg_qkv": (i32, [C.POINTER(QkvParams), vp]),
+    "ovg_flash_attn": (i32, [C.POINTER(AttnParams), vp]),
+    "ovg_block_forward": (i32, [C.POINTER(BlockParams), vp]),
+    "ovg_block_attn_prologue": (i32, [C.POINTER(BlockParams), vp]),
+    "ovg_block_attn_epilogue": (i32, [C.POINTER(BlockParams), vp]),
+    "ovg_im2col": (i32, [C.POINTER(Im2colParams), vp]),
+    "ovg_depth_stats": (i32, [C.POINTER(DepthStatsParams), vp]),
+    "ovg_dino_specials": (i32, [C.POINTER(DinoSpecialsParams), vp]),
+    "ovg_assemble_tokens": (i32, [C.POINTER(AssembleParams), vp]),
+    "ovg_copy_rows": (i32, [C.POINTER(CopyRowsParams), vp]),
+    "ovg_probe_mfma": (i32, [vp, vp, vp, i32, vp]),
+}
+
+
+class OvgError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load(build_if_missing=True):
+    """Load the shared library (building it in-tree with hipcc if it is absent)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise OvgError("libomnivggt_hip.so is missing (run __graft_entry__.build()); there is no fallback path")
+        from .build import build
+        build()
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)      # AttributeError here == ABI mismatch, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ovg_abi_version() != ABI_VERSION:
+        raise OvgError("ABI version mismatch: library %d, binding %d" % (lib.ovg_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise OvgError("%s failed: %s (%d)" % (what, ERRORS.get(rc, "?"), rc))
+
+
+def call(name, params, stream):
+    """Invoke `name(&params, stream)`; raises OvgError on a non-zero return code."""
+    lib = load()
+    rc = getattr(lib, name)(C.byref(params), stream)
+    check(rc, name)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def dtype_code(torch_dtype):
+    import torch
+    return {torch.bfloat16: OVG_BF16, torch.float16: OVG_F16, torch.float32: OVG_F32}[torch_dtype]
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise OvgError("no HIP device visible: the aggregator hot path has no CPU fallback")

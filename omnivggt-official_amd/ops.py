@@ -1,0 +1,167 @@
+"""Torch-tensor front ends of the C ABI entries (one function per `ovg_*` kernel entry).
+
+They only marshal device pointers, shapes and the current HIP stream into the parameter
+structs of include/omnivggt_hip.h; every byte of compute happens in libomnivggt_hip.so.
+"""
+import torch
+
+from . import lib as L
+
+C, H, D, HID = 1024, 16, 64, 4096
+KV_TILE = L.KV_TILE
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.OvgError("expected a HIP device tensor (the hot path has no CPU fallback)")
+
+
+def layernorm(x, weight, bias, eps, dtype, out=None, out_f32=False):
+    """x: f32 [rows, 1024] (row-strided view allowed) -> [rows,1024] in dtype (or f32)."""
+    _chk_dev(x, weight, bias)
+    rows = x.shape[0]
+    if out is None:
+        out = torch.empty(rows, C, device=x.device, dtype=torch.float32 if out_f32 else dtype)
+    p = L.LayerNormParams(L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), L.ptr(weight), L.ptr(bias), rows, eps,
+                          L.dtype_code(dtype), 1 if out_f32 else 0)
+    L.call("ovg_layernorm", p, _stream())
+    return out
+
+
+def linear(x, w, bias, dtype, epilogue=L.EPI_STORE, out=None, out_f32=False, res=None, gamma=None, inject=None,
+           inj_period=0, table=None, p0=0, p1=0, row_off=0, out_rows=None):
+    """y = epilogue(x @ w.T + bias); x [M,K], w [N,K] in dtype."""
+    _chk_dev(x, w, bias, res, gamma, inject, table, out)
+    M, K = x.shape
+    N = w.shape[0]
+    f32_out = out_f32 or epilogue in (L.EPI_RES, L.EPI_PATCH)
+    if out is None:
+        out = torch.empty(out_rows if out_rows is not None else M, N, device=x.device, dtype=torch.float32 if f32_out else dtype)
+    p = L.LinearParams()
+    p.x, p.ldx, p.w, p.ldw, p.bias = L.ptr(x), x.stride(0), L.ptr(w), w.stride(0), L.ptr(bias)
+    p.y, p.ldy, p.M, p.N, p.K = L.ptr(out), out.stride(0), M, N, K
+    p.dtype, p.epilogue, p.out_f32 = L.dtype_code(dtype), epilogue, 1 if f32_out else 0
+    if res is not None:
+        p.res, p.ldres = L.ptr(res), res.stride(0)
+    p.gamma, p.inject, p.inj_period = L.ptr(gamma), L.ptr(inject), inj_period
+    p.table, p.p0, p.p1, p.row_off = L.ptr(table), p0, p1, row_off
+    L.call("ovg_linear", p, _stream())
+    return out
+
+
+def alloc_qkv(BH, nq, nk, dtype, device):
+    """Zero-filled head-major buffers q [BH,nq_pad,64], k [BH,nk_pad,64], vt [BH,64,nk_pad]."""
+    nq_pad, nk_pad = pad_to(nq, KV_TILE), pad_to(nk, KV_TILE)
+    q = torch.zeros(BH, nq_pad, D, device=device, dtype=dtype)
+    k = torch.zeros(BH, nk_pad, D, device=device, dtype=dtype)
+    vt = torch.zeros(BH, D, nk_pad, device=device, dtype=dtype)
+    return q, k, vt
+
+
+def qkv(x, w, bias, seq, dtype, q, k, vt, qk_norm=None, rope=None, tokens_per_view=1374, grid_w=37, n_special=5,
+        q_scale=0.125 * 1.4426950408889634, qk_eps=1e-5):
+    """Fused QKV projection.  qk_norm = (qn_w, qn_b, kn_w, kn_b) or None; rope = (cos, sin) or None."""
+    _chk_dev(x, w, bias, q, k, vt)
+    p = L.QkvParams()
+    p.x, p.ldx, p.w, p.bias = L.ptr(x), x.stride(0), L.ptr(w), L.ptr(bias)
+    p.q, p.k, p.vt = L.ptr(q), L.ptr(k), L.ptr(vt)
+    p.M, p.seq, p.nq_pad, p.nk_pad, p.dtype = x.shape[0], seq, q.shape[1], k.shape[1], L.dtype_code(dtype)
+    if qk_norm is not None:
+        p.qk_norm = 1
+        p.qn_w, p.qn_b, p.kn_w, p.kn_b = (L.ptr(t) for t in qk_norm)
+    p.qk_eps = qk_eps
+    if rope is not None:
+        p.rope = 1
+        p.rope_cos, p.rope_sin, p.max_pos = L.ptr(rope[0]), L.ptr(rope[1]), rope[0].shape[0]
+    p.tokens_per_view, p.grid_w, p.n_special, p.q_scale = tokens_per_view, grid_w, n_special, q_scale
+    L.call("ovg_qkv", p, _stream())
+
+
+def flash_attn(q, segments, nq, dtype, out=None, variant=0):
+    """q [BH,nq_pad,64]; segments: list of (k [BH,nk_pad,64], vt [BH,64,nk_pad], nk).
+    Returns out [B*nq, 1024] token-major."""
+    _chk_dev(q)
+    BH = q.shape[0]
+    if out is None:
+        out = torch.empty((BH // H) * nq, C, device=q.device, dtype=dtype)
+    p = L.AttnParams()
+    p.q, p.nq, p.nq_pad, p.nseg = L.ptr(q), nq, q.shape[1], len(segments)
+    for i, (k, vt, nk) in enumerate(segments):
+        _chk_dev(k, vt)
+        p.seg[i].k, p.seg[i].vt, p.seg[i].nk, p.seg[i].nk_pad = L.ptr(k), L.ptr(vt), nk, k.shape[1]
+    p.out, p.ldo, p.BH, p.dtype, p.variant = L.ptr(out), out.stride(0), BH, L.dtype_code(dtype), variant
+    L.call("ovg_flash_attn", p, _stream())
+    return out
+
+
+def im2col_rgb(images, dtype, k_pad=640, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """images f32 [V,3,H,W] -> [V*gh*gw, k_pad] normalised patches."""
+    _chk_dev(images)
+    V, Cc, Hp, Wp = images.shape
+    out = torch.empty(V * (Hp // 14) * (Wp // 14), k_pad, device=images.device, dtype=dtype)
+    p = L.Im2colParams()
+    p.img, p.out, p.k_pad, p.V, p.C, p.Hpx, p.Wpx = L.ptr(images), L.ptr(out), k_pad, V, Cc, Hp, Wp
+    p.dtype, p.mode = L.dtype_code(dtype), 0
+    for i in range(3):
+        p.mean[i], p.std[i] = mean[i], std[i]
+    L.call("ovg_im2col", p, _stream())
+    return out
+
+
+def depth_stats(depth, mask):
+    """depth, mask f32 [B, n] -> f64 [B,2] = {masked sum, count} (deterministic two-stage)."""
+    _chk_dev(depth, mask)
+    B, n = depth.shape
+    nblocks = 256
+    stats = torch.empty(B, 2, device=depth.device, dtype=torch.float64)
+    partial = torch.empty(B * nblocks * 2, device=depth.device, dtype=torch.float64)
+    p = L.DepthStatsParams(L.ptr(depth), L.ptr(mask), B, n, L.ptr(stats), L.ptr(partial), nblocks)
+    L.call("ovg_depth_stats", p, _stream())
+    return stats
+
+
+def im2col_depth(depth, mask, stats, views_per_batch, dtype, k_pad=448):
+    """depth, mask f32 [V,H,W]; stats f64 [B,2] -> [V*gh*gw, k_pad] (channels: normalised depth, mask)."""
+    _chk_dev(depth, mask, stats)
+    V, Hp, Wp = depth.shape
+    out = torch.empty(V * (Hp // 14) * (Wp // 14), k_pad, device=depth.device, dtype=dtype)
+    p = L.Im2colParams()
+    p.img, p.img2, p.out, p.k_pad, p.V, p.C, p.Hpx, p.Wpx = L.ptr(depth), L.ptr(mask), L.ptr(out), k_pad, V, 2, Hp, Wp
+    p.dtype, p.mode, p.depth_stats, p.views_per_batch = L.dtype_code(dtype), 1, L.ptr(stats), views_per_batch
+    L.call("ovg_im2col", p, _stream())
+    return out
+
+
+def dino_specials(x, V, tokens_per_view, cls, pos0, reg):
+    _chk_dev(x, cls, pos0, reg)
+    p = L.DinoSpecialsParams(L.ptr(x), x.stride(0), V, tokens_per_view, L.ptr(cls), L.ptr(pos0), L.ptr(reg), reg.shape[0])
+    L.call("ovg_dino_specials", p, _stream())
+
+
+def assemble_tokens(xd, norm_w, norm_b, eps, camera_token, register_token, cam_add, depth_tok, depth_row, placeholder,
+                    out, V, S, tokens_per_view=1374, n_special=5, view0=0):
+    _chk_dev(xd, out)
+    p = L.AssembleParams()
+    p.xd, p.ldxd, p.norm_w, p.norm_b, p.eps = L.ptr(xd), xd.stride(0), L.ptr(norm_w), L.ptr(norm_b), eps
+    p.camera_token, p.register_token, p.cam_add = L.ptr(camera_token), L.ptr(register_token), L.ptr(cam_add)
+    p.depth_tok, p.depth_row, p.placeholder = L.ptr(depth_tok), L.ptr(depth_row), L.ptr(placeholder)
+    p.out, p.ldo, p.V, p.S, p.tokens_per_view, p.n_special = L.ptr(out), out.stride(0), V, S, tokens_per_view, n_special
+    p.view0 = view0
+    L.call("ovg_assemble_tokens", p, _stream())
+
+
+def probe_mfma(a_frag, b_frag, dtype_code):
+    """a_frag, b_frag: int32 [64,4] raw fragments -> f32 [64,4] accumulator of one 16x16 MFMA."""
+    out = torch.empty(64, 4, device=a_frag.device, dtype=torch.float32)
+    rc = L.load().ovg_probe_mfma(L.ptr(a_frag), L.ptr(b_frag), L.ptr(out), dtype_code, _stream())
+    L.check(rc, "ovg_probe_mfma")
+    return out

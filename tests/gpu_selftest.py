@@ -1,0 +1,430 @@
+"""Kernel-by-kernel GPU self test + micro-benchmark (run on the MI355X box):
+
+    python tests/gpu_selftest.py [--quick] [--bench]
+
+Each HIP kernel is called through the C ABI and compared with a plain PyTorch CPU fp32
+evaluation of the same op on the same (dtype-rounded) inputs.  Prints one line per check
+with the max abs / max rel error so a failure can be diagnosed from the log alone.
+This is a diagnostic tool; the pytest suite (tests/test_gpu_*.py) holds the gated checks.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+from omnivggt_official_amd import lib as L, ops  # noqa: E402
+import aggregator_oracle as orc  # noqa: E402
+
+DEV = "cuda"
+DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+TOL = {"bf16": 2e-2, "f16": 4e-3, "f32": 2e-5}
+results = []
+
+
+def report(name, got, ref, tol):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    bad = ~torch.isfinite(got)
+    diff = (got - ref).abs()
+    diff[bad] = float("inf")
+    mx = float(diff.max())
+    scale = float(ref.abs().max())
+    rel = mx / max(scale, 1e-30)
+    ok = rel <= tol
+    where = ""
+    if not ok:
+        idx = int(diff.flatten().argmax())
+        unr = []
+        for s in reversed(got.shape):
+            unr.append(idx % s)
+            idx //= s
+        nbad = int((diff > tol * scale).sum())
+        where = " worst@%s got=%g ref=%g nbad=%d/%d nonfinite=%d" % (list(reversed(unr)), float(got.flatten()[int(diff.flatten().argmax())]),
+                                                                   float(ref.flatten()[int(diff.flatten().argmax())]), nbad, diff.numel(), int(bad.sum()))
+    print("[%s] %-46s max_abs=%.3e ref_max=%.3e rel=%.3e tol=%.1e%s" % ("PASS" if ok else "FAIL", name, mx, scale, rel, tol, where), flush=True)
+    results.append({"name": name, "ok": bool(ok), "rel": rel})
+    return ok
+
+
+def rnd(*shape, g, scale=1.0):
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ---------------------------------------------------------------------------
+def test_probe():
+    """MFMA lane maps assumed by the kernels: A row = lane&15, B col = lane&15,
+    C[row = 4*(lane>>4)+r][col = lane&15]; A and B share the k assignment."""
+    g = torch.Generator().manual_seed(1)
+    for name, code, per, tdt in (("bf16", L.OVG_BF16, 8, torch.bfloat16), ("f16", L.OVG_F16, 8, torch.float16), ("f32", L.OVG_F32, 4, torch.float32)):
+        Kd = per * 4
+        A = torch.randint(-4, 5, (16, Kd), generator=g).float()
+        B = torch.randint(-4, 5, (16, Kd), generator=g).float()   # B^T rows: B[n][k]
+        # lane l: row l&15, chunk l>>4 (k = per*(l>>4) .. +per)
+        af = torch.stack([A[l & 15, per * (l >> 4): per * (l >> 4) + per] for l in range(64)]).to(tdt).contiguous()
+        bf = torch.stack([B[l & 15, per * (l >> 4): per * (l >> 4) + per] for l in range(64)]).to(tdt).contiguous()
+        out = ops.probe_mfma(af.to(DEV).view(torch.int32).view(64, 4), bf.to(DEV).view(torch.int32).view(64, 4), code).cpu()
+        Cm = A @ B.t()      # C[i][j] = sum_k A[i][k] B[j][k]
+        exp = torch.stack([torch.stack([Cm[4 * (l >> 4) + r, l & 15] for r in range(4)]) for l in range(64)])
+        ok = report("probe_mfma_%s (C[4g+r][lane&15])" % name, out, exp, 0.0)
+        if not ok:
+            expT = torch.stack([torch.stack([Cm[l & 15, 4 * (l >> 4) + r] for r in range(4)]) for l in range(64)])
+            print("   transposed hypothesis matches:", bool(torch.equal(out, expT)))
+            print("   out[:8]=", out[:8].tolist())
+            print("   exp[:8]=", exp[:8].tolist())
+
+
+def test_layernorm():
+    g = torch.Generator().manual_seed(2)
+    rows = 1374 * 2 + 3
+    big = rnd(rows, 2048, g=g, scale=2.0) + 0.3
+    x = big[:, 1024:]                                  # strided view (ld = 2048)
+    w, b = rnd(1024, g=g) * 0.1 + 1, rnd(1024, g=g) * 0.1
+    ref = F.layer_norm(x, (1024,), w, b, 1e-5)
+    xd = big.to(DEV)[:, 1024:]
+    for name, dt in DT.items():
+        y = ops.layernorm(xd, w.to(DEV), b.to(DEV), 1e-5, dt)
+        report("layernorm_%s" % name, y, ref, TOL[name] if name != "f32" else 2e-6)
+    y = ops.layernorm(xd, w.to(DEV), b.to(DEV), 1e-6, torch.bfloat16, out_f32=True)
+    report("layernorm_out_f32_eps1e-6", y, F.layer_norm(x, (1024,), w, b, 1e-6), 2e-6)
+
+
+def test_linear(quick):
+    g = torch.Generator().manual_seed(3)
+    for name, dt in DT.items():
+        for (M, N, K) in ((300, 256, 128), (1374 * 2, 1024, 1024)) if not quick else ((300, 256, 128),):
+            x = rnd(M, K, g=g).to(dt)
+            w = (rnd(N, K, g=g) * 0.05).to(dt)
+            bias = rnd(N, g=g)
+            xf, wf = x.float(), w.float()
+            base = xf @ wf.t() + bias
+            xd, wd, bd = x.to(DEV), w.to(DEV), bias.to(DEV)
+            tol = TOL[name]
+            y = ops.linear(xd, wd, bd, dt)
+            report("linear_store_%s_%dx%dx%d" % (name, M, N, K), y, base, tol)
+            y = ops.linear(xd, wd, bd, dt, out_f32=True)
+            report("linear_store_f32out_%s_%dx%dx%d" % (name, M, N, K), y, base, 2e-5 if name != "f32" else 2e-6)
+            y = ops.linear(xd, wd, bd, dt, epilogue=L.EPI_GELU)
+            report("linear_gelu_%s_%dx%dx%d" % (name, M, N, K), y, F.gelu(base), tol)
+            res = rnd(M, 2 * N, g=g)
+            gamma = rnd(N, g=g)
+            per = 137
+            inj = rnd((M + per - 1) // per, N, g=g)
+            ref = res[:, N:] + gamma * base
+            ref2 = ref.clone()
+            ref2[::per] += inj[: ref2[::per].shape[0]]
+            resd = res.to(DEV)
+            out = torch.zeros(M, 2 * N, device=DEV)
+            ops.linear(xd, wd, bd, dt, epilogue=L.EPI_RES, out=out[:, :N], res=resd[:, N:], gamma=gamma.to(DEV))
+            report("linear_res_%s_%dx%dx%d" % (name, M, N, K), out[:, :N], ref, 2e-5 if name != "f32" else 2e-6)
+            if N == 1024:
+                ops.linear(xd, wd, bd, dt, epilogue=L.EPI_RES, out=out[:, :N], res=resd[:, N:], gamma=gamma.to(DEV), inject=inj.to(DEV), inj_period=per)
+                report("linear_res_inject_%s_%dx%dx%d" % (name, M, N, K), out[:, :N], ref2, 2e-5 if name != "f32" else 2e-6)
+        # PATCH epilogue: M = 2 views * 100 patches -> rows (v*105 + 5 + t)
+        p0, p1 = 100, 105
+        M, N, K = 2 * p0, 1024, 640
+        x = rnd(M, K, g=g).to(dt)
+        w = (rnd(N, K, g=g) * 0.05).to(dt)
+        bias = rnd(N, g=g)
+        table = rnd(p0 + 1, N, g=g)
+        base = x.float() @ w.float().t() + bias
+        ref = torch.zeros(2 * p1, N)
+        for v in range(2):
+            ref[v * p1 + 5: v * p1 + 5 + p0] = base[v * p0:(v + 1) * p0] + table[1:]
+        out = torch.zeros(2 * p1, N, device=DEV)
+        ops.linear(x.to(DEV), w.to(DEV), bias.to(DEV), dt, epilogue=L.EPI_PATCH, out=out, table=table.to(DEV), p0=p0, p1=p1, row_off=5)
+        report("linear_patch_%s" % name, out, ref, 2e-5 if name != "f32" else 2e-6)
+
+
+def qkv_reference(x, w, bias, seq, qk_norm, rope, tokens_per_view, grid_w):
+    """attention.py:52-58 on CPU: returns q (scaled), k, v as [B,H,N,64]."""
+    M = x.shape[0]
+    B = M // seq
+    qkv = (x @ w.t() + bias).reshape(B, seq, 3, 16, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    if qk_norm is not None:
+        q = F.layer_norm(q, (64,), qk_norm[0], qk_norm[1], 1e-5)
+        k = F.layer_norm(k, (64,), qk_norm[2], qk_norm[3], 1e-5)
+    if rope is not None:
+        t = torch.arange(M) % tokens_per_view
+        pp = (t - 5).clamp(min=0)
+        py = torch.where(t >= 5, pp // grid_w + 1, torch.zeros_like(t))
+        px = torch.where(t >= 5, pp % grid_w + 1, torch.zeros_like(t))
+        pos = torch.stack([py, px], -1).reshape(B, seq, 2)
+        q = orc.rope_2d(q, pos, *rope)
+        k = orc.rope_2d(k, pos, *rope)
+    return q * (0.125 * 1.4426950408889634), k, v
+
+
+def test_qkv(quick):
+    g = torch.Generator().manual_seed(4)
+    tpv, gw = 1374, 37
+    cos, sin = orc.rope_tables(38)
+    cos16, sin16 = cos[:, :16].contiguous(), sin[:, :16].contiguous()
+    for name, dt in DT.items():
+        for mode, nviews in (("frame", 2), ("global", 2)):
+            M = nviews * tpv
+            seq = tpv if mode == "frame" else M
+            x = rnd(M, 1024, g=g).to(dt)
+            w = (rnd(3072, 1024, g=g) * 0.03).to(dt)
+            bias = rnd(3072, g=g) * 0.1
+            qn = [rnd(64, g=g) * 0.1 + 1.5, rnd(64, g=g) * 0.1, rnd(64, g=g) * 0.1 + 1.5, rnd(64, g=g) * 0.1]
+            for variant in (("norm_rope", qn, (cos, sin)), ("plain", None, None)):
+                vn, qk_norm, rope = variant
+                qr, kr, vr = qkv_reference(x.float(), w.float(), bias, seq, qk_norm, rope, tpv, gw)
+                BH = (M // seq) * 16
+                q, k, vt = ops.alloc_qkv(BH, seq, seq, dt, DEV)
+                ops.qkv(x.to(DEV), w.to(DEV), bias.to(DEV), seq, dt, q, k, vt,
+                        qk_norm=None if qk_norm is None else [t.to(DEV) for t in qk_norm],
+                        rope=None if rope is None else (cos16.to(DEV), sin16.to(DEV)))
+                tol = TOL[name] * (2 if name != "f32" else 5)
+                report("qkv_%s_%s_%s.q" % (name, mode, vn), q[:, :seq], qr.reshape(BH, seq, 64), tol)
+                report("qkv_%s_%s_%s.k" % (name, mode, vn), k[:, :seq], kr.reshape(BH, seq, 64), tol)
+                report("qkv_%s_%s_%s.vt" % (name, mode, vn), vt[:, :, :seq], vr.reshape(BH, seq, 64).transpose(1, 2), tol)
+                pad_clean = float(q[:, seq:].abs().max()) == 0.0 and float(vt[:, :, seq:].abs().max()) == 0.0
+                if not pad_clean:
+                    print("[FAIL] qkv padding was written")
+            if quick:
+                break
+
+
+def attn_reference(q, k, v):
+    """q pre-scaled by scale*log2e: softmax base 2."""
+    s = (q @ k.transpose(-1, -2)) * math.log(2.0)
+    return torch.softmax(s, dim=-1) @ v
+
+
+def test_attn(quick):
+    g = torch.Generator().manual_seed(5)
+    for name, dt in DT.items():
+        cases = [("n1374_bh32", 32, 1374, [1374], 0), ("n2748_2seg", 16, 2748 // 2, [1374, 1374], 0),
+                 ("n700_ragged_seg", 16, 700, [100, 333, 64], 0)]
+        if name != "f32":
+            cases += [("n1374_bh16_qb2", 16, 1374, [1374], 2), ("n300_qb2_seg", 16, 300, [130, 70], 2)]
+        if quick:
+            cases = cases[:2]
+        for cname, BH, nq, nks, variant in cases:
+            q = (rnd(BH, nq, 64, g=g) * 1.2).to(dt)
+            ks = [(rnd(BH, nk, 64, g=g)).to(dt) for nk in nks]
+            vs = [(rnd(BH, nk, 64, g=g)).to(dt) for nk in nks]
+            ref = attn_reference(q.float(), torch.cat(ks, 1).float(), torch.cat(vs, 1).float())   # [BH,nq,64]
+            ref_tok = ref.reshape(BH // 16, 16, nq, 64).permute(0, 2, 1, 3).reshape(-1, 1024)
+            qd, _, _ = ops.alloc_qkv(BH, nq, 64, dt, DEV)
+            qd[:, :nq] = q.to(DEV)
+            segs = []
+            for kk, vv in zip(ks, vs):
+                nk = kk.shape[1]
+                _, kd, vtd = ops.alloc_qkv(BH, 64, nk, dt, DEV)
+                kd[:, :nk] = kk.to(DEV)
+                vtd[:, :, :nk] = vv.transpose(1, 2).to(DEV)
+                segs.append((kd, vtd, nk))
+            out = ops.flash_attn(qd, segs, nq, dt, variant=variant)
+            report("attn_%s_%s" % (name, cname), out, ref_tok, TOL[name])
+        # forced-rescale case: one key spikes against one query late in the sequence
+        BH, nq, nk = 16, 128, 640
+        q = rnd(BH, nq, 64, g=g).to(dt)
+        k = rnd(BH, nk, 64, g=g).to(dt)
+        v = rnd(BH, nk, 64, g=g).to(dt)
+        k[:, 500] = (q[:, 7].float() * 6).to(dt)
+        ref = attn_reference(q.float(), k.float(), v.float()).reshape(1, 16, nq, 64).permute(0, 2, 1, 3).reshape(-1, 1024)
+        qd, kd, vtd = ops.alloc_qkv(BH, nq, nk, dt, DEV)
+        qd[:, :nq] = q.to(DEV)
+        kd[:, :nk] = k.to(DEV)
+        vtd[:, :, :nk] = v.transpose(1, 2).to(DEV)
+        out = ops.flash_attn(qd, [(kd, vtd, nk)], nq, dt)
+        report("attn_%s_spike_rescale" % name, out, ref, TOL[name])
+
+
+def test_embed():
+    g = torch.Generator().manual_seed(6)
+    V, Hp = 2, 518
+    img = torch.rand(V, 3, Hp, Hp, generator=g)
+    mean = torch.tensor(orc.RESNET_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(orc.RESNET_STD).view(1, 3, 1, 1)
+    xn = (img - mean) / std
+    cols = F.unfold(xn, kernel_size=14, stride=14).transpose(1, 2).reshape(V * 1369, 588)
+    for name, dt in DT.items():
+        out = ops.im2col_rgb(img.to(DEV), dt)
+        report("im2col_rgb_%s" % name, out[:, :588], cols, 1e-2 if name == "bf16" else (1e-3 if name == "f16" else 1e-6))
+        if float(out[:, 588:].abs().max()) != 0:
+            print("[FAIL] im2col pad not zero")
+    depth = 0.5 + 5 * torch.rand(V, Hp, Hp, generator=g)
+    mask = (torch.rand(V, Hp, Hp, generator=g) > 0.2).float()
+    stats = ops.depth_stats(depth.reshape(1, -1).to(DEV), mask.reshape(1, -1).to(DEV)).cpu()
+    valid = depth[mask > 0]
+    report("depth_stats.sum", stats[:, 0], valid.double().sum().reshape(1), 1e-9)
+    report("depth_stats.count", stats[:, 1], torch.tensor([float(valid.numel())]), 0.0)
+    dn = orc.normalize_depth(depth.reshape(1, V, Hp, Hp, 1), mask.reshape(1, V, Hp, Hp)).reshape(V, 1, Hp, Hp)
+    maps = torch.cat([dn, mask.reshape(V, 1, Hp, Hp)], dim=1)
+    cols = F.unfold(maps, kernel_size=14, stride=14).transpose(1, 2).reshape(V * 1369, 392)
+    out = ops.im2col_depth(depth.to(DEV), mask.to(DEV), stats.to(DEV), V, torch.float32)
+    report("im2col_depth_f32", out[:, :392], cols, 2e-6)
+    # dino specials + assemble
+    P, S = 1374, 2
+    x = torch.zeros(V * P, 1024, device=DEV)
+    cls, pos0, reg = rnd(1024, g=g), rnd(1024, g=g), rnd(4, 1024, g=g)
+    ops.dino_specials(x, V, P, cls.to(DEV), pos0.to(DEV), reg.to(DEV))
+    ref = torch.zeros(V, P, 1024)
+    ref[:, 0] = cls + pos0
+    ref[:, 1:5] = reg
+    report("dino_specials", x.view(V, P, 1024), ref, 0.0)
+    xd = rnd(V * P, 1024, g=g)
+    nw, nb = rnd(1024, g=g) * 0.1 + 1, rnd(1024, g=g) * 0.1
+    cam, regt = rnd(2, 1024, g=g), rnd(2, 4, 1024, g=g)
+    cam_add = rnd(V, 1024, g=g)
+    dtok = rnd(1 * 1369, 1024, g=g)
+    drow = torch.tensor([-1, 0], dtype=torch.int32)
+    ph = rnd(1024, g=g)
+    out = torch.zeros(V * P, 1024, device=DEV)
+    ops.assemble_tokens(xd.to(DEV), nw.to(DEV), nb.to(DEV), 1e-6, cam.to(DEV), regt.to(DEV), cam_add.to(DEV), dtok.to(DEV),
+                        drow.to(DEV), ph.to(DEV), out, V, S)
+    ln = F.layer_norm(xd.view(V, P, 1024), (1024,), nw, nb, 1e-6)
+    ref = torch.zeros(V, P, 1024)
+    ref[0, 0] = cam[0] + cam_add[0]
+    ref[1, 0] = cam[1] + cam_add[1]
+    ref[0, 1:5], ref[1, 1:5] = regt[0], regt[1]
+    ref[0, 5:] = ln[0, 5:] + ph
+    ref[1, 5:] = ln[1, 5:] + dtok
+    report("assemble_tokens", out.view(V, P, 1024), ref, 2e-6)
+
+
+def test_block(quick):
+    """One frame block and one global block through ovg_block_forward vs oracle.block."""
+    from omnivggt_official_amd import aggregator as agg
+    g = torch.Generator().manual_seed(7)
+    S, P = 2, 1374
+    keys = {}
+    for nm, shape in (("norm1.weight", (1024,)), ("norm1.bias", (1024,)), ("attn.qkv.weight", (3072, 1024)), ("attn.qkv.bias", (3072,)),
+                      ("attn.q_norm.weight", (64,)), ("attn.q_norm.bias", (64,)), ("attn.k_norm.weight", (64,)), ("attn.k_norm.bias", (64,)),
+                      ("attn.proj.weight", (1024, 1024)), ("attn.proj.bias", (1024,)), ("ls1.gamma", (1024,)),
+                      ("norm2.weight", (1024,)), ("norm2.bias", (1024,)), ("mlp.fc1.weight", (4096, 1024)), ("mlp.fc1.bias", (4096,)),
+                      ("mlp.fc2.weight", (1024, 4096)), ("mlp.fc2.bias", (1024,)), ("ls2.gamma", (1024,))):
+        from omnivggt_official_amd import weights
+        keys["blk." + nm] = weights.draw("aggregator.frame_blocks.0." + nm, shape, seed=5)
+    x = rnd(S * P, 1024, g=g)
+    pos_yx = torch.cartesian_prod(torch.arange(37), torch.arange(37)) + 1
+    pos = torch.cat([torch.zeros(5, 2, dtype=pos_yx.dtype), pos_yx]).unsqueeze(0).expand(S, -1, -1)
+    rope = orc.rope_tables(38)
+    inj = rnd(S, 1024, g=g)
+    for name, dt in DT.items():
+        if quick and name == "f16":
+            continue
+        for mode in ("frame", "global"):
+            if mode == "frame":
+                ref = orc.block(x.view(S, P, 1024), keys, "blk", pos, rope, True).reshape(S * P, 1024).clone()
+                ref[::P] += inj
+            else:
+                ref = orc.block(x.view(1, S * P, 1024), keys, "blk", pos.reshape(1, S * P, 2), rope, True).reshape(S * P, 1024)
+            runner = agg.BlockRunner(keys, "blk", dt, DEV, qk_norm=True, rope=True, ln_eps=1e-5)
+            ws = agg.Workspace(S * P, P if mode == "frame" else S * P, dt, DEV)
+            buf = torch.zeros(S * P, 2048, device=DEV)
+            xin = x.to(DEV)
+            runner.forward(ws, xin, buf[:, 1024:], inject=inj.to(DEV) if mode == "frame" else None, inj_period=P)
+            tol = {"bf16": 3e-2, "f16": 6e-3, "f32": 5e-5}[name]
+            report("block_%s_%s" % (name, mode), buf[:, 1024:], ref, tol)
+
+
+def bench(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def microbench():
+    print("---- micro-benchmarks (bf16, random data) ----", flush=True)
+    g = torch.Generator().manual_seed(9)
+    dt = torch.bfloat16
+    out = {}
+    for S in (8, 16):
+        M = S * 1374
+        x = rnd(M, 1024, g=g).to(dt).to(DEV)
+        for nm, N, K in (("qkv-shape", 3072, 1024), ("proj", 1024, 1024), ("fc1", 4096, 1024), ("fc2", 1024, 4096)):
+            xx = x if K == 1024 else rnd(M, K, g=g).to(dt).to(DEV)
+            w = (rnd(N, K, g=g) * 0.03).to(dt).to(DEV)
+            b = torch.zeros(N, device=DEV)
+            y = torch.empty(M, N, device=DEV, dtype=dt)
+            ms = bench(lambda: ops.linear(xx, w, b, dt, out=y))
+            tf = 2.0 * M * N * K / ms / 1e9
+            print("gemm %-10s S=%d M=%d N=%d K=%d: %.3f ms  %.1f TFLOP/s" % (nm, S, M, N, K, ms, tf), flush=True)
+            out["gemm_%s_S%d" % (nm, S)] = {"ms": ms, "tflops": tf}
+        # global attention
+        for variant in (1, 2):
+            BH, n = 16, M
+            q, k, vt = ops.alloc_qkv(BH, n, n, dt, DEV)
+            q[:, :n] = rnd(BH, n, 64, g=g).to(dt).to(DEV)
+            k[:, :n] = rnd(BH, n, 64, g=g).to(dt).to(DEV)
+            vt[:, :, :n] = rnd(BH, 64, n, g=g).to(dt).to(DEV)
+            o = torch.empty(n, 1024, device=DEV, dtype=dt)
+            ms = bench(lambda: ops.flash_attn(q, [(k, vt, n)], n, dt, out=o, variant=variant), iters=5)
+            tf = 4.0 * n * n * 1024 / ms / 1e9
+            print("global attn S=%d N=%d variant(QB)=%d: %.3f ms  %.1f TFLOP/s (%.1f%% of 2.5 PF)" % (S, n, variant, ms, tf, tf / 25.0), flush=True)
+            out["gattn_S%d_qb%d" % (S, variant)] = {"ms": ms, "tflops": tf}
+        # frame attention
+        for variant in (1, 2):
+            BH, n = S * 16, 1374
+            q, k, vt = ops.alloc_qkv(BH, n, n, dt, DEV)
+            q[:, :n] = rnd(BH, n, 64, g=g).to(dt).to(DEV)
+            k[:, :n] = rnd(BH, n, 64, g=g).to(dt).to(DEV)
+            vt[:, :, :n] = rnd(BH, 64, n, g=g).to(dt).to(DEV)
+            o = torch.empty(S * n, 1024, device=DEV, dtype=dt)
+            ms = bench(lambda: ops.flash_attn(q, [(k, vt, n)], n, dt, out=o, variant=variant), iters=5)
+            tf = 4.0 * BH * n * n * 64 / ms / 1e9
+            print("frame attn S=%d variant(QB)=%d: %.3f ms  %.1f TFLOP/s" % (S, variant, ms, tf), flush=True)
+            out["fattn_S%d_qb%d" % (S, variant)] = {"ms": ms, "tflops": tf}
+        xf = rnd(M, 1024, g=g).to(DEV)
+        w1 = torch.ones(1024, device=DEV)
+        y = torch.empty(M, 1024, device=DEV, dtype=dt)
+        ms = bench(lambda: ops.layernorm(xf, w1, w1, 1e-5, dt, out=y))
+        print("layernorm S=%d: %.3f ms  %.1f GB/s" % (S, ms, M * 1024 * 6 / ms / 1e6), flush=True)
+        out["ln_S%d" % S] = {"ms": ms}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--bench", action="store_true")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    L.require_gpu()
+    print(L.load().ovg_build_info().decode(), torch.cuda.get_device_name(0), flush=True)
+    tests = {"probe": test_probe, "layernorm": test_layernorm, "linear": lambda: test_linear(args.quick), "qkv": lambda: test_qkv(args.quick),
+             "attn": lambda: test_attn(args.quick), "embed": test_embed, "block": lambda: test_block(args.quick)}
+    for name, fn in tests.items():
+        if args.only and name not in args.only.split(","):
+            continue
+        t0 = time.time()
+        try:
+            fn()
+        except Exception as e:  # keep going: one log should show every problem
+            import traceback
+            traceback.print_exc()
+            print("[FAIL] %s raised %r" % (name, e), flush=True)
+            results.append({"name": name + "_exception", "ok": False, "rel": float("nan")})
+        torch.cuda.synchronize()
+        print("  (%s: %.1fs)" % (name, time.time() - t0), flush=True)
+    nfail = sum(1 for r in results if not r["ok"])
+    print("SELFTEST: %d checks, %d failed" % (len(results), nfail), flush=True)
+    mb = microbench() if args.bench else {}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump({"results": results, "microbench": mb}, open(os.path.join(ROOT, "gpurun_out", "selftest.json"), "w"), indent=1)
+    return 1 if nfail else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
