@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""Benchmark of the OmniVGGT aggregator hot path on MI355X (contract: see the task prompt).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--views S] [--dtype bf16|f16|f32]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE forward of the aggregator (DINOv2 embed + modality fusion + 24 x [frame block,
+camera injection, global block]) over one synthetic multi-view batch already resident in HBM.
+N=1: BASELINE.json configs[1] (8 views, 518^2, images-only, bf16).  N>1: 8 views per GPU
+(view-sharded, K/V^T all-gather over RCCL) -- N=8 is configs[3] (64 views); "scaling":"weak"
+means views per GPU are fixed (global-attention work per view still grows with S, so the
+JSON also carries algorithmic TFLOP/s per GPU).  --views overrides the total view count
+(e.g. --views 64 at every N for the strong-scaling curve of the north star).
+
+Prints ONE JSON line on rank 0 (metric frames/s, roofline of the global-attention kernel
+measured live with HIP events inside the timed steps, cpu_baseline = oracle on host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from omnivggt_official_amd import lib as L, weights  # noqa: E402
+from omnivggt_official_amd.model import OmniVGGT  # noqa: E402
+
+P_TOK, C = 1374, 1024
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}     # MI355X_MICROARCH.md, dense MFMA
+DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+
+
+def agg_flops(S):
+    """F(S) and F_ga(S) for B=1 (FLOP)."""
+    f_ga = 96.0 * (S * P_TOK) ** 2 * 1024
+    return S * (72 * 34.58e9 + 48 * 7.73e9 + 1.65e9) + f_ga, f_ga
+
+
+def synthetic_inputs(S, device, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    images = torch.rand(1, S, 3, 518, 518, generator=g)
+    z = lambda *s: torch.zeros(*s)
+    return dict(images=images.to(device), extrinsics=z(1, S, 3, 4).to(device), intrinsics=z(1, S, 3, 3).to(device),
+                depth=z(1, S, 518, 518, 1).to(device), mask=z(1, S, 518, 518).to(device))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--views", type=int, default=0, help="total views S (default 8 per GPU)")
+    ap.add_argument("--dtype", default="bf16", choices=list(DT))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--attn-variant", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (one process per GPU)" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    L.require_gpu()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    S = args.views or 8 * world
+    dtype = DT[args.dtype]
+    with torch.device("meta"):
+        model = OmniVGGT(compute_dtype=dtype)
+    manifest = weights.manifest_of(model)
+    sd = weights.synthetic_state_dict(manifest, seed=2)
+    model = model.to_empty(device="cpu")
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    agg = model.aggregator
+    agg.attn_variant = args.attn_variant
+    if world > 1:
+        from omnivggt_official_amd.sharding import ViewSharding
+        agg.shard = ViewSharding(gather_output=False)
+    inp = synthetic_inputs(S, dev)
+
+    # live HIP-event timing of the global-attention launches inside the timed steps
+    n_local = S // world + (1 if rank < S % world else 0)
+    nq_local, nk_total = n_local * P_TOK, S * P_TOK
+    ev = agg.enable_attention_events(args.steps * agg.depth)
+
+    def step():
+        return agg(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], [], [])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    agg.reset_attention_events()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    attn_ms = agg.attention_event_times()
+    agg.disable_attention_events()
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        a = torch.tensor([sum(attn_ms) / max(len(attn_ms), 1)], device=dev, dtype=torch.float64)
+        dist.all_reduce(a, op=dist.ReduceOp.MAX)
+        attn_avg_ms = float(a.item())
+    else:
+        attn_avg_ms = sum(attn_ms) / max(len(attn_ms), 1)
+
+    ms_per_step = dt / args.steps * 1e3
+    fps = S * args.steps / dt
+    f_total, f_ga = agg_flops(S)
+    launch_flops = 4.0 * nq_local * nk_total * 1024           # one global-attention launch on this rank
+    achieved = launch_flops / (attn_avg_ms * 1e-3) / 1e12 if attn_avg_ms > 0 else 0.0
+    peak = PEAK_TFLOPS[args.dtype]
+
+    result = {
+        "metric": "frames/sec (518^2, S views) aggregator hot path", "value": round(fps, 3), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "OmniVGGT aggregator forward, %d views 518x518 images-only (BASELINE configs[%s]), %d views/GPU, "
+                               "view-sharded global attention" % (S, "1" if world == 1 and S == 8 else ("3" if S == 64 else "-"), n_local),
+                   "views": S, "views_per_gpu": n_local, "tokens": S * P_TOK, "weights": "seeded synthetic (no checkpoint offline)",
+                   "parallelism": "view-shard x%d" % world},
+        "algorithmic_tflop_per_step": round(f_total / 1e12, 2),
+        "tflops_per_gpu": round(f_total / 1e12 / (dt / args.steps) / world, 1),
+        "roofline": {"bound": "mfma", "kernel": "attn_kernel (global attention, D=64)", "achieved": round(achieved, 1), "peak": peak,
+                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                     "flop_per_launch": launch_flops, "avg_launch_ms": round(attn_avg_ms, 4), "launches_timed": len(attn_ms)},
+    }
+
+    if rank == 0 and world == 1:
+        tr = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tr):
+            try:
+                result["roofline"]["traffic"] = json.load(open(tr)).get("global_attn_S%d_bytes_per_launch" % S)
+            except Exception:
+                pass
+        if not args.no_e2e:
+            try:
+                full = lambda: model(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], [], [])
+                full()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    full()
+                torch.cuda.synchronize()
+                result["e2e_frames_per_s_with_pytorch_heads"] = round(S * 2 / (time.perf_counter() - t1), 3)
+            except Exception as e:  # heads are stock PyTorch; never let them hide the hot-path number
+                result["e2e_error"] = repr(e)[:200]
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(sd)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sd, S=2):
+    """Oracle (CPU restatement, bit-exact vs the reference's PyTorch CPU path) on the host cores:
+    a bounded sample -- the full 24-layer aggregator on S=2 views (~10-30 s)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import aggregator_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    inp = orc.synthetic_inputs(S)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        orc.aggregator_forward(sd, inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], [], [])
+        dt = time.perf_counter() - t0
+    return {"value": round(S / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "oracle aggregator forward (fp32, torch CPU, %d threads), S=%d views 518^2 images-only, 1 run, %.1f s" % (cores, S, dt)}
+
+
+if __name__ == "__main__":
+    main()

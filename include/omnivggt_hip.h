@@ -119,6 +119,7 @@ typedef struct {
   int rope; const float* rope_cos; const float* rope_sin; int max_pos;
   int64_t tokens_per_view; int grid_w; int n_special;
   float q_scale;
+  int part;   /* 0 = q,k,v; 1 = k and v only; 2 = q only (sharded path: K/V first, all-gather || Q) */
 } ovg_qkv_params;
 int ovg_qkv(const ovg_qkv_params*, void* stream);
 
@@ -183,6 +184,10 @@ typedef struct {
    * between ovg_block_attn_prologue and ovg_block_attn_epilogue. */
   ovg_kv_segment extra[OVG_MAX_SEG]; int nseg_extra; int local_seg_index;
   int attn_variant;
+  int qkv_part;  /* ovg_block_attn_prologue only: 0 = LN1 + q,k,v; 1 = LN1 + k,v; 2 = q only (no LN) */
+  /* optional hipEvent_t handles recorded on `stream` immediately before / after the
+   * flash-attention launch (bench.py: live per-kernel timing); NULL = not recorded */
+  void* ev_attn_start; void* ev_attn_stop;
 } ovg_block_params;
 /* whole block */
 int ovg_block_forward(const ovg_block_params*, void* stream);

@@ -151,9 +151,12 @@ class BlockRunner:
         p.attn_variant = self.attn_variant
         return p
 
-    def forward(self, ws, x_in, x_out, inject=None, inj_period=0, **kw):
-        """x_in/x_out: f32 [M,1024] row-strided views (x_out may alias x_in)."""
+    def forward(self, ws, x_in, x_out, inject=None, inj_period=0, events=None, **kw):
+        """x_in/x_out: f32 [M,1024] row-strided views (x_out may alias x_in).
+        events: optional (start, stop) torch.cuda.Event pair recorded around the attention launch."""
         p = self.params(ws, x_in, x_out, inject, inj_period, **kw)
+        if events is not None:
+            p.ev_attn_start, p.ev_attn_stop = events[0].cuda_event, events[1].cuda_event
         L.call("ovg_block_forward", p, torch.cuda.current_stream().cuda_stream)
 
 
@@ -207,6 +210,34 @@ class ZeroAggregator(nn.Module):
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
 
     # ------------------------------------------------------------------
+    # live per-kernel timing of the global-attention launches (bench.py roofline)
+    def enable_attention_events(self, n):
+        self._events = []
+        for _ in range(n):
+            pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            pair[0].record()
+            pair[1].record()          # materialise the hipEvent_t handles
+            self._events.append(pair)
+        self._event_i = 0
+        return self._events
+
+    def reset_attention_events(self):
+        self._event_i = 0
+
+    def next_attention_events(self):
+        ev = getattr(self, "_events", None)
+        if not ev or self._event_i >= len(ev):
+            return None
+        self._event_i += 1
+        return ev[self._event_i - 1]
+
+    def attention_event_times(self):
+        """ms of every recorded global-attention launch since reset (device must be synchronised)."""
+        return [a.elapsed_time(b) for a, b in getattr(self, "_events", [])[: getattr(self, "_event_i", 0)]]
+
+    def disable_attention_events(self):
+        self._events, self._event_i = [], 0
+
     def invalidate(self):
         self._packed = None
         self._ws = {}
@@ -372,6 +403,6 @@ class ZeroAggregator(nn.Module):
             for i in range(self.depth):
                 buf = outs[i].view(T, 2 * C)
                 pk["frame"][i].forward(ws_f, x, buf[:, :C], inject=tables[i + 1], inj_period=P)
-                pk["global"][i].forward(ws_g, buf[:, :C], buf[:, C:])
+                pk["global"][i].forward(ws_g, buf[:, :C], buf[:, C:], events=self.next_attention_events())
                 x = buf[:, C:]
         return outs, self.patch_start_idx

@@ -15,15 +15,19 @@ int check_block(const ovg_block_params* p) {
   return OVG_OK;
 }
 
-int run_prologue(const ovg_block_params* p, void* st) {
+int run_prologue(const ovg_block_params* p, void* st, int part) {
+  int rc = OVG_OK;
+  if (part != 2) {
   ovg_layernorm_params ln{};
   ln.x = p->x_in; ln.ldx = p->ld_in; ln.y = p->ws_xn; ln.ldy = OVG_C;
   ln.weight = static_cast<const float*>(p->w.n1_w); ln.bias = static_cast<const float*>(p->w.n1_b);
   ln.rows = p->M; ln.eps = p->ln_eps; ln.dtype = p->dtype; ln.out_f32 = 0;
-  int rc = ovg_layernorm(&ln, st);
+  rc = ovg_layernorm(&ln, st);
   if (rc) return rc;
+  }
 
   ovg_qkv_params q{};
+  q.part = part;
   q.x = p->ws_xn; q.ldx = OVG_C; q.w = p->w.qkv_w; q.bias = p->w.qkv_b;
   q.q = p->ws_q; q.k = p->ws_k; q.vt = p->ws_vt;
   q.M = p->M; q.seq = p->seq; q.nq_pad = p->nq_pad; q.nk_pad = p->nk_pad; q.dtype = p->dtype;
@@ -44,7 +48,9 @@ int run_epilogue(const ovg_block_params* p, void* st) {
     else a.seg[i] = p->extra[e++];
   }
   a.out = p->ws_attn; a.ldo = OVG_C; a.BH = p->BH; a.dtype = p->dtype; a.variant = p->attn_variant;
+  if (p->ev_attn_start) (void)hipEventRecord(static_cast<hipEvent_t>(p->ev_attn_start), static_cast<hipStream_t>(st));
   int rc = ovg_flash_attn(&a, st);
+  if (p->ev_attn_stop) (void)hipEventRecord(static_cast<hipEvent_t>(p->ev_attn_stop), static_cast<hipStream_t>(st));
   if (rc) return rc;
 
   ovg_linear_params l{};
@@ -80,7 +86,7 @@ int run_epilogue(const ovg_block_params* p, void* st) {
 
 extern "C" int ovg_block_attn_prologue(const ovg_block_params* p, void* stream) {
   int rc = check_block(p);
-  return rc ? rc : run_prologue(p, stream);
+  return rc ? rc : run_prologue(p, stream, p->qkv_part);
 }
 extern "C" int ovg_block_attn_epilogue(const ovg_block_params* p, void* stream) {
   int rc = check_block(p);
@@ -89,6 +95,6 @@ extern "C" int ovg_block_attn_epilogue(const ovg_block_params* p, void* stream) 
 extern "C" int ovg_block_forward(const ovg_block_params* p, void* stream) {
   int rc = check_block(p);
   if (rc) return rc;
-  rc = run_prologue(p, stream);
+  rc = run_prologue(p, stream, 0);
   return rc ? rc : run_epilogue(p, stream);
 }

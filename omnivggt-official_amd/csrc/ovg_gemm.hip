@@ -158,12 +158,12 @@ __global__ __launch_bounds__(256) void linear_kernel(ovg_linear_params p, int nt
 // QKV kernel: bias + per-head LayerNorm(64) + 2-D RoPE + q scale, head-major stores
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void qkv_kernel(ovg_qkv_params p) {
+__global__ __launch_bounds__(256) void qkv_kernel(ovg_qkv_params p, int nt_begin, int nt_count) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128];
-  constexpr int N = 3 * OVG_C, K = OVG_C, NT = N / BN;
+  constexpr int N = 3 * OVG_C, K = OVG_C;
   const int M = (int)p.M;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (bid / NT) * BM, n0 = (bid % NT) * BN;
+  const int m0 = (bid / nt_count) * BM, n0 = (nt_begin + bid % nt_count) * BN;
   f32x4 acc[4][4];
   gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
 
@@ -324,12 +324,16 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
     const int64_t np = p->tokens_per_view - p->n_special;
     if (np <= 0 || (np - 1) / p->grid_w + 1 >= p->max_pos || p->grid_w >= p->max_pos) return OVG_E_ARG;
   }
-  const dim3 grid((unsigned)(((p->M + BM - 1) / BM) * (3 * OVG_C / BN))), block(256);
+  if (p->part < 0 || p->part > 2) return OVG_E_ARG;
+  const int q_tiles = OVG_C / BN, all_tiles = 3 * OVG_C / BN;
+  const int nt_begin = p->part == 1 ? q_tiles : 0;
+  const int nt_count = p->part == 0 ? all_tiles : (p->part == 1 ? all_tiles - q_tiles : q_tiles);
+  const dim3 grid((unsigned)(((p->M + BM - 1) / BM) * nt_count)), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (p->dtype) {
-    case OVG_BF16: hipLaunchKernelGGL((qkv_kernel<bf16_t>), grid, block, 0, st, *p); break;
-    case OVG_F16: hipLaunchKernelGGL((qkv_kernel<f16_t>), grid, block, 0, st, *p); break;
-    case OVG_F32: hipLaunchKernelGGL((qkv_kernel<float>), grid, block, 0, st, *p); break;
+    case OVG_BF16: hipLaunchKernelGGL((qkv_kernel<bf16_t>), grid, block, 0, st, *p, nt_begin, nt_count); break;
+    case OVG_F16: hipLaunchKernelGGL((qkv_kernel<f16_t>), grid, block, 0, st, *p, nt_begin, nt_count); break;
+    case OVG_F32: hipLaunchKernelGGL((qkv_kernel<float>), grid, block, 0, st, *p, nt_begin, nt_count); break;
     default: return OVG_E_DTYPE;
   }
   OVG_CHECK_LAUNCH();

@@ -38,7 +38,7 @@ class QkvParams(C.Structure):
                 ("M", i64), ("seq", i64), ("nq_pad", i64), ("nk_pad", i64), ("dtype", i32),
                 ("qk_norm", i32), ("qn_w", vp), ("qn_b", vp), ("kn_w", vp), ("kn_b", vp), ("qk_eps", f32),
                 ("rope", i32), ("rope_cos", vp), ("rope_sin", vp), ("max_pos", i32),
-                ("tokens_per_view", i64), ("grid_w", i32), ("n_special", i32), ("q_scale", f32)]
+                ("tokens_per_view", i64), ("grid_w", i32), ("n_special", i32), ("q_scale", f32), ("part", i32)]
 
 
 class KvSegment(C.Structure):
@@ -66,7 +66,7 @@ class BlockParams(C.Structure):
                 ("inject", vp), ("inj_period", i64),
                 ("ws_xn", vp), ("ws_q", vp), ("ws_k", vp), ("ws_vt", vp), ("ws_attn", vp), ("ws_hid", vp),
                 ("extra", KvSegment * OVG_MAX_SEG), ("nseg_extra", i32), ("local_seg_index", i32),
-                ("attn_variant", i32)]
+                ("attn_variant", i32), ("qkv_part", i32), ("ev_attn_start", vp), ("ev_attn_stop", vp)]
 
 
 class Im2colParams(C.Structure):

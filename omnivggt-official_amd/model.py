@@ -1,0 +1,84 @@
+"""OmniVGGT facade with the reference's constructor / forward / state-dict contract
+(omnivggt/models/omnivggt.py:10-68), the aggregator replaced by the gfx950 HIP path.
+
+    model = OmniVGGT()                               # no torch.hub call, no network
+    model.load_state_dict(load_file("OmniVGGT.safetensors"), strict=True)
+    model = model.to("cuda").eval()
+    out = model(images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index)
+
+`compute_dtype` selects the aggregator arithmetic: torch.bfloat16 (default, throughput),
+torch.float16, or torch.float32 (parity mode: exact-f32 MFMA, matches the reference CPU
+path to ~1e-5 relative).  Heads always run in f32, like the reference (autocast disabled,
+omnivggt.py:45).
+"""
+import torch
+import torch.nn as nn
+
+from .aggregator import ZeroAggregator
+from .heads import CameraHead, DPTHead
+
+try:  # the reference mixes in huggingface_hub.PyTorchModelHubMixin (omnivggt.py:3,10)
+    from huggingface_hub import PyTorchModelHubMixin as _HubMixin
+except Exception:  # pragma: no cover - optional
+    class _HubMixin:  # type: ignore
+        pass
+
+
+class OmniVGGT(nn.Module, _HubMixin):
+    def __init__(self, img_size=518, patch_size=14, embed_dim=1024, depth=24, dino_depth=24,
+                 compute_dtype=torch.bfloat16, dpt_layers=(4, 11, 17, 23)):
+        super().__init__()
+        self.aggregator = ZeroAggregator(img_size=img_size, patch_size=patch_size, embed_dim=embed_dim, depth=depth,
+                                         dino_depth=dino_depth, pose_hidden_dim=9, compute_dtype=compute_dtype)
+        layers = tuple(min(l, depth - 1) for l in dpt_layers)
+        self.camera_head = CameraHead(dim_in=2 * embed_dim)
+        self.point_head = DPTHead(dim_in=2 * embed_dim, output_dim=4, activation="inv_log", conf_activation="expp1",
+                                  intermediate_layer_idx=layers)
+        self.depth_head = DPTHead(dim_in=2 * embed_dim, output_dim=2, activation="exp", conf_activation="expp1",
+                                  intermediate_layer_idx=layers)
+
+    def set_compute_dtype(self, dtype):
+        self.aggregator.set_compute_dtype(dtype)
+        return self
+
+    def forward(self, images, extrinsics=None, intrinsics=None, depth=None, mask=None, depth_gt_index=None,
+                camera_gt_index=None):
+        if images.dim() == 4:
+            images = images.unsqueeze(0)
+        # the reference dereferences these unconditionally (omnivggt_aggregator.py:158-185); accept the
+        # loader's "absent modality" convention (zero tensors + empty lists, visual_util.py:793-824)
+        depth_gt_index = list(depth_gt_index) if depth_gt_index is not None else []
+        camera_gt_index = list(camera_gt_index) if camera_gt_index is not None else []
+        if depth_gt_index and (depth is None or mask is None):
+            raise ValueError("depth_gt_index given without depth/mask tensors")
+        if camera_gt_index and (extrinsics is None or intrinsics is None):
+            raise ValueError("camera_gt_index given without extrinsics/intrinsics tensors")
+
+        tokens, patch_start_idx = self.aggregator(images=images, extrinsics=extrinsics, intrinsics=intrinsics, depth=depth,
+                                                  mask=mask, depth_gt_index=depth_gt_index, camera_gt_index=camera_gt_index)
+        out = {}
+        shard = self.aggregator.shard
+        sharded = shard is not None and not shard.gather_output
+        with torch.no_grad(), torch.amp.autocast("cuda", enabled=False):
+            imgs32 = images.float()
+            cam_tokens = tokens
+            if sharded:
+                # tokens are this rank's views only: the camera head attends across ALL views, so
+                # gather the (S,2C) camera tokens of the last layer; DPT heads are per-frame.
+                parts = shard.last_partition
+                lo, hi = parts[shard.rank]
+                cam_tokens = [shard.gather_views(tokens[-1][:, :, :1].contiguous(), parts)]
+                imgs32 = imgs32[:, lo:hi]
+            if self.camera_head is not None:
+                poses = self.camera_head(cam_tokens)
+                out["pose_enc"], out["pose_enc_list"] = poses[-1], poses
+            if self.depth_head is not None:
+                out["depth"], out["depth_conf"] = self.depth_head(tokens, images=imgs32, patch_start_idx=patch_start_idx)
+            if self.point_head is not None:
+                out["world_points"], out["world_points_conf"] = self.point_head(tokens, images=imgs32, patch_start_idx=patch_start_idx)
+            if sharded:
+                for key in ("depth", "depth_conf", "world_points", "world_points_conf"):
+                    if key in out:
+                        out[key] = shard.gather_views(out[key].contiguous(), parts)
+        out["images"] = images
+        return out

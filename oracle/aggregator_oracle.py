@@ -203,13 +203,9 @@ def scatter_rows(values, B, S, index, K, width):
 # ----------------------------------------------------------------------------
 # the aggregator
 # ----------------------------------------------------------------------------
-def aggregator_forward(sd, images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index,
-                       depth_layers=24, dino_layers=24, capture=None):
-    """models/omnivggt_aggregator.py:130-305 + models/aggregator.py:312-341.
-
-    Returns (list of depth_layers tensors (B,S,P,2C), patch_start_idx).  `capture`, if a
-    dict, receives intermediate tensors ("tokens0", "dino").
-    """
+def aggregator_prepare(sd, images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index, dino_layers=24):
+    """Embedding + modality fusion, models/omnivggt_aggregator.py:130-224.
+    Returns dict(tokens (K,T,C), pos (K,T,2), rope, enc, B, S)."""
     P = "aggregator"
     B, S, C_in, H, W = images.shape
     if C_in != 3:
@@ -219,24 +215,16 @@ def aggregator_forward(sd, images, extrinsics, intrinsics, depth, mask, depth_gt
     x = ((images - mean) / std).view(B * S, C_in, H, W)
     patch_tokens = dino_backbone(x, sd, P + ".patch_embed", dino_layers)
     K, P0, C = patch_tokens.shape
-    if capture is not None:
-        capture["dino"] = patch_tokens
 
     cam_tok = special_tokens(sd[P + ".camera_token"], B, S)
     reg_tok = special_tokens(sd[P + ".register_token"], B, S)
 
-    def lin(name, i, v):
-        return F.linear(v, sd["%s.%s.%d.weight" % (P, name, i)], sd["%s.%s.%d.bias" % (P, name, i)])
-
-    have_cam = len(camera_gt_index) != 0
-    if have_cam:
+    if len(camera_gt_index) != 0:
         idx = torch.tensor(camera_gt_index)
         ext_n = normalize_extrinsics(torch.index_select(extrinsics, 1, idx))
         enc = pose_encoding(ext_n, torch.index_select(intrinsics, 1, idx), (H, W))
-        cam_full = scatter_rows(lin("pose_embeddings", 0, enc), B, S, camera_gt_index, K, C)
     else:
         enc = None
-        cam_full = torch.zeros(K, 1, C)
 
     if len(depth_gt_index) != 0:
         idx = torch.tensor(depth_gt_index)
@@ -252,31 +240,55 @@ def aggregator_forward(sd, images, extrinsics, intrinsics, depth, mask, depth_gt
     else:
         depth_full = sd[P + ".depth_placeholder"].expand(K, P0, C)
 
-    cam_tok = cam_tok + lin("camera_adapters", 0, cam_full)
-    tokens = torch.cat([cam_tok, reg_tok, patch_tokens + depth_full], dim=1)
-    if capture is not None:
-        capture["tokens0"] = tokens
+    st = dict(B=B, S=S, K=K, C=C, enc=enc, camera_gt_index=list(camera_gt_index))
+    cam_tok = cam_tok + camera_injection(sd, 0, st)
+    st["tokens"] = torch.cat([cam_tok, reg_tok, patch_tokens + depth_full], dim=1)
 
     gh, gw = H // PATCH, W // PATCH
     yx = torch.cartesian_prod(torch.arange(gh), torch.arange(gw)) + 1        # layers/rope.py:39-59 (+1: :219)
     pos = torch.cat([torch.zeros(N_SPECIAL, 2, dtype=yx.dtype), yx], dim=0)
-    pos = pos.unsqueeze(0).expand(K, -1, -1)
-    rope = rope_tables(int(pos.max()) + 1)
-    T = tokens.shape[1]
+    st["pos"] = pos.unsqueeze(0).expand(K, -1, -1)
+    st["rope"] = rope_tables(int(pos.max()) + 1)
+    return st
 
+
+def camera_injection(sd, i, st):
+    """camera_adapters[i](scatter(pose_embeddings[i](enc))) -> (K,1,C)
+    (omnivggt_aggregator.py:172-178,211 for i=0; :273-287 for i>=1).  Views without a GT
+    camera receive the adapter bias (Linear of a zero row)."""
+    P = "aggregator"
+
+    def lin(name, v):
+        return F.linear(v, sd["%s.%s.%d.weight" % (P, name, i)], sd["%s.%s.%d.bias" % (P, name, i)])
+
+    if st["enc"] is not None:
+        src = scatter_rows(lin("pose_embeddings", st["enc"]), st["B"], st["S"], st["camera_gt_index"], st["K"], st["C"])
+    else:
+        src = torch.zeros(st["K"], 1, st["C"])
+    return lin("camera_adapters", src)
+
+
+def aggregator_forward(sd, images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index,
+                       depth_layers=24, dino_layers=24, capture=None):
+    """models/omnivggt_aggregator.py:130-305 + models/aggregator.py:312-341.
+
+    Returns (list of depth_layers tensors (B,S,P,2C), patch_start_idx).  `capture`, if a
+    dict, receives intermediate tensors ("tokens0").
+    """
+    st = aggregator_prepare(sd, images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index, dino_layers)
+    B, S, K, C = st["B"], st["S"], st["K"], st["C"]
+    tokens, pos, rope = st["tokens"], st["pos"], st["rope"]
+    if capture is not None:
+        capture["tokens0"] = tokens
+    T = tokens.shape[1]
     out = []
     for i in range(depth_layers):
         # frame attention + camera injection (omnivggt_aggregator.py:258-305)
-        tokens = block(tokens.view(K, T, C), sd, "%s.frame_blocks.%d" % (P, i), pos, rope, True)
-        if have_cam:
-            inj_src = scatter_rows(lin("pose_embeddings", i + 1, enc), B, S, camera_gt_index, K, C)
-        else:
-            inj_src = torch.zeros(K, 1, C)
-        inj = lin("camera_adapters", i + 1, inj_src)
-        tokens = torch.cat([tokens[:, :1] + inj, tokens[:, 1:]], dim=1)
+        tokens = block(tokens.view(K, T, C), sd, "aggregator.frame_blocks.%d" % i, pos, rope, True)
+        tokens = torch.cat([tokens[:, :1] + camera_injection(sd, i + 1, st), tokens[:, 1:]], dim=1)
         frame_out = tokens.view(B, S, T, C)
         # global attention (aggregator.py:312-341)
-        tokens = block(tokens.view(B, S * T, C), sd, "%s.global_blocks.%d" % (P, i), pos.reshape(B, S * T, 2), rope, True)
+        tokens = block(tokens.view(B, S * T, C), sd, "aggregator.global_blocks.%d" % i, pos.reshape(B, S * T, 2), rope, True)
         out.append(torch.cat([frame_out, tokens.view(B, S, T, C)], dim=-1))
     return out, N_SPECIAL
 

@@ -1,0 +1,140 @@
+"""CPU-side checks (no GPU): state-dict contract, C ABI surface, struct layout, loud failure
+without a device, host-side camera math and heads vs the oracle."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+import torch
+
+import aggregator_oracle as orc
+from omnivggt_official_amd import camera_math, heads, lib as L, weights
+from omnivggt_official_amd.aggregator import ZeroAggregator
+from omnivggt_official_amd.model import OmniVGGT
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "omnivggt_hip.h")
+MANIFEST = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_manifest.json")))
+
+
+def test_state_dict_keys_match_reference_manifest():
+    """1505 keys / shapes of the reference checkpoint contract (inference.py:323-324)."""
+    with torch.device("meta"):
+        m = OmniVGGT()
+    mine = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert len(MANIFEST) == 1505
+    assert mine == MANIFEST
+
+
+def test_depth_reduced_manifest_is_a_subset():
+    with torch.device("meta"):
+        m = OmniVGGT(depth=2, dino_depth=3)
+    mine = {k: list(v.shape) for k, v in m.state_dict().items()}
+    red = weights.reduce_manifest(MANIFEST, depth=2, dino_depth=3)
+    assert mine == {k: list(v) for k, v in red.items()}
+
+
+def test_library_exports_every_declared_symbol():
+    text = open(HEADER).read()
+    declared = set(re.findall(r"\b(ovg_[a-z0-9_]+)\s*\(", text))
+    assert declared, "no prototypes parsed"
+    lib = L.load()
+    for name in declared:
+        assert hasattr(lib, name), "missing export " + name
+    assert declared == set(L.SYMBOLS), (declared ^ set(L.SYMBOLS))
+    assert lib.ovg_abi_version() == L.ABI_VERSION
+    assert b"gfx950" in lib.ovg_build_info()
+
+
+def test_ctypes_struct_layout_matches_c():
+    """sizeof() of every params struct as gcc sees the header == the ctypes mirror."""
+    pairs = {"ovg_layernorm_params": L.LayerNormParams, "ovg_linear_params": L.LinearParams, "ovg_qkv_params": L.QkvParams,
+             "ovg_kv_segment": L.KvSegment, "ovg_attn_params": L.AttnParams, "ovg_block_weights": L.BlockWeights,
+             "ovg_block_params": L.BlockParams, "ovg_im2col_params": L.Im2colParams, "ovg_depth_stats_params": L.DepthStatsParams,
+             "ovg_dino_specials_params": L.DinoSpecialsParams, "ovg_assemble_params": L.AssembleParams,
+             "ovg_copy_rows_params": L.CopyRowsParams}
+    src = '#include <stdio.h>\n#include "%s"\nint main(){\n' % HEADER
+    for name in pairs:
+        src += 'printf("%s %%zu\\n", sizeof(%s));\n' % (name, name)
+    src += "return 0;}\n"
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["gcc", "-std=c99", c, "-o", exe])
+        out = subprocess.check_output([exe]).decode()
+    sizes = dict(line.split() for line in out.strip().splitlines())
+    for name, cls in pairs.items():
+        assert int(sizes[name]) == ctypes.sizeof(cls), name
+
+
+def test_argument_validation_without_gpu():
+    """Entry points reject bad arguments before touching the device."""
+    lib = L.load()
+    p = L.LinearParams()
+    assert lib.ovg_linear(ctypes.byref(p), None) == -1
+    a = L.AttnParams()
+    assert lib.ovg_flash_attn(ctypes.byref(a), None) == -1
+    assert lib.ovg_qkv(None, None) == -1
+
+
+def test_hot_path_fails_loudly_on_cpu():
+    agg = ZeroAggregator(pose_hidden_dim=9, depth=1, dino_depth=1)
+    x = torch.zeros(1, 2, 3, 518, 518)
+    with pytest.raises(L.OvgError):
+        agg(x, None, None, None, None, [], [])
+    with pytest.raises(ValueError):
+        agg(torch.zeros(1, 2, 4, 518, 518), None, None, None, None, [], [])
+
+
+def test_camera_math_matches_oracle():
+    inp = orc.synthetic_inputs(5)
+    a = camera_math.normalize_extrinsics(inp["extrinsics"])
+    b = orc.normalize_extrinsics(inp["extrinsics"])
+    assert torch.equal(a, b)
+    assert torch.equal(camera_math.pose_encoding(a, inp["intrinsics"], (518, 518)), orc.pose_encoding(b, inp["intrinsics"], (518, 518)))
+    enc = camera_math.pose_encoding(a, inp["intrinsics"], (518, 518))
+    ext, K = camera_math.pose_decoding(enc, (518, 518))
+    assert torch.allclose(ext, a, atol=1e-5)
+    assert torch.allclose(K[..., 0, 0], inp["intrinsics"][..., 0, 0], rtol=1e-5)
+
+
+def test_partition_is_contiguous_and_complete():
+    from omnivggt_official_amd.sharding import partition
+    for n, w in ((8, 8), (64, 8), (10, 4), (3, 2), (128, 8), (9, 8)):
+        parts = partition(n, w)
+        assert parts[0][0] == 0 and parts[-1][1] == n
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+        sizes = [h - l for l, h in parts]
+        assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 1
+
+
+def test_heads_match_oracle_on_cpu():
+    """Product heads (nn.Module) vs the oracle's functional restatement, same synthetic weights."""
+    man = {k: v for k, v in MANIFEST.items() if not k.startswith("aggregator.")}
+    sd = weights.synthetic_state_dict(man, seed=3)
+    cam = heads.CameraHead(dim_in=2048)
+    cam.load_state_dict({k[len("camera_head."):]: v for k, v in sd.items() if k.startswith("camera_head.")}, strict=True)
+    dh = heads.DPTHead(dim_in=2048, output_dim=2, activation="exp")
+    dh.load_state_dict({k[len("depth_head."):]: v for k, v in sd.items() if k.startswith("depth_head.")}, strict=True)
+    ph = heads.DPTHead(dim_in=2048, output_dim=4, activation="inv_log")
+    ph.load_state_dict({k[len("point_head."):]: v for k, v in sd.items() if k.startswith("point_head.")}, strict=True)
+    g = torch.Generator().manual_seed(0)
+    S = 2
+    toks = [torch.randn(1, S, 1374, 2048, generator=g) for _ in range(24)]
+    images = torch.rand(1, S, 3, 518, 518, generator=g)
+    with torch.no_grad():
+        mine = cam(toks)
+        ref = orc.camera_head_forward(sd, toks[-1])
+        for a, b in zip(mine, ref):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+        d, dc = dh(toks, images, 5)
+        rd, rdc = orc.dpt_head_forward(sd, "depth_head", toks, images, 5, activation="exp")
+        assert torch.allclose(d, rd, rtol=1e-4, atol=1e-6) and torch.allclose(dc, rdc, rtol=1e-4, atol=1e-6)
+        p, pc = ph(toks, images, 5)
+        rp, rpc = orc.dpt_head_forward(sd, "point_head", toks, images, 5, activation="inv_log")
+        assert torch.allclose(p, rp, rtol=1e-4, atol=1e-6) and torch.allclose(pc, rpc, rtol=1e-4, atol=1e-6)
+        assert d.shape == (1, S, 518, 518, 1) and pc.shape == (1, S, 518, 518)

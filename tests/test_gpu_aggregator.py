@@ -1,0 +1,144 @@
+"""-m gpu: the HIP aggregator / OmniVGGT facade against the CPU oracle and the committed
+golden vectors of the real reference.
+
+Tolerances (max|a-b| / max|b| per tensor):
+  f32 parity mode : <= 1e-4 on every aggregator layer and on pose_enc / depth / points
+  bf16 / f16 modes: reported next to the f32 oracle; gated loosely (tokens <= 0.2 / 0.05) because
+                    with the sensitised weights the reference itself moves 7e-2..1e-1 under
+                    torch.autocast(bf16) -- the 1e-4 target is an fp32 statement.
+"""
+import os
+
+import pytest
+import torch
+
+import aggregator_oracle as orc
+import common
+from omnivggt_official_amd import lib as L
+from omnivggt_official_amd.model import OmniVGGT
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+F32_TOL = 1e-4
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    L.require_gpu()
+    torch.set_num_threads(os.cpu_count())
+
+
+def build(sd, depth, dino_depth, dtype):
+    with torch.device("meta"):
+        m = OmniVGGT(depth=depth, dino_depth=dino_depth, compute_dtype=dtype)
+    m = m.to_empty(device="cpu")
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV).eval()
+
+
+def run_model(m, S, dgi, cgi):
+    inp = common.inputs_for(S, DEV)
+    with torch.no_grad():
+        toks, start = m.aggregator(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
+        out = m(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
+    return toks, start, out
+
+
+@pytest.fixture(scope="module")
+def reduced():
+    sd = common.reduced_state_dict(2, 2)
+    return sd, build(sd, 2, 2, torch.float32)
+
+
+@pytest.mark.parametrize("S,dgi,cgi", [(2, [], []), (2, [1], []), (3, [], [0, 2]), (3, [1], [0, 2]), (2, [0, 1], [0, 1])])
+def test_f32_parity_all_modality_combos_depth2(reduced, S, dgi, cgi):
+    """depth-2 / DINO-2 model, every modality combination incl. partial / interleaved indices."""
+    sd, m = reduced
+    inp = orc.synthetic_inputs(S)
+    with torch.no_grad():
+        ref = orc.model_forward(sd, inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi,
+                                depth_layers=2, dino_layers=2)
+    toks, start, out = run_model(m, S, dgi, cgi)
+    assert start == 5 and len(toks) == 2
+    for l in range(2):
+        assert toks[l].shape == (1, S, 1374, 2048) and toks[l].dtype == torch.float32
+        assert common.max_rel(toks[l].cpu(), ref["_tokens"][l]) <= F32_TOL
+    for key in ("pose_enc", "depth", "depth_conf", "world_points", "world_points_conf"):
+        assert out[key].shape == ref[key].shape
+        assert common.max_rel(out[key].cpu(), ref[key]) <= F32_TOL, key
+    assert len(out["pose_enc_list"]) == 4 and out["images"].shape == (1, S, 3, 518, 518)
+
+
+@pytest.fixture(scope="module")
+def full_f32():
+    sd = common.full_state_dict()
+    return build(sd, 24, 24, torch.float32)
+
+
+@pytest.mark.parametrize("name", ["s2_images_only", "s3_partial_aux", "s2_full_aux"])
+def test_f32_full_depth_vs_reference_golden(full_f32, name):
+    """Full 24+24+24-block model in f32 parity mode against the REAL reference's outputs."""
+    S, dgi, cgi = common.CASES[name]
+    toks, start, out = run_model(full_f32, S, dgi, cgi)
+    gold = common.load_golden(name)
+    worst = 0.0
+    for l in common.TOK_LAYERS:
+        e = common.max_rel(common.sample_tokens([t.cpu() for t in toks], l), gold["tok_L%d" % l])
+        worst = max(worst, e)
+        assert e <= F32_TOL, (l, e)
+    absmean = torch.tensor([float(t.abs().mean()) for t in toks])
+    assert common.max_rel(absmean, gold["tok_absmean"]) <= F32_TOL
+    assert common.max_rel(out["pose_enc"].cpu(), gold["pose_enc"]) <= F32_TOL
+    assert common.max_rel(out["depth"][0, :, ::37, ::37, 0].cpu(), gold["depth"]) <= F32_TOL
+    assert common.max_rel(out["depth_conf"][0, :, ::37, ::37].cpu(), gold["depth_conf"]) <= F32_TOL
+    assert common.max_rel(out["world_points"][0, :, ::37, ::37].cpu(), gold["world_points"]) <= F32_TOL
+    print("f32 full-depth %s: worst sampled token max-rel %.2e" % (name, worst))
+
+
+@pytest.mark.parametrize("dtype,tok_tol", [(torch.bfloat16, 0.2), (torch.float16, 0.05)])
+def test_low_precision_modes_vs_golden(dtype, tok_tol):
+    sd = common.full_state_dict()
+    m = build(sd, 24, 24, dtype)
+    S, dgi, cgi = common.CASES["s3_partial_aux"]
+    toks, start, out = run_model(m, S, dgi, cgi)
+    gold = common.load_golden("s3_partial_aux")
+    errs = {l: common.max_rel(common.sample_tokens([t.cpu() for t in toks], l), gold["tok_L%d" % l]) for l in common.TOK_LAYERS}
+    pe = common.max_rel(out["pose_enc"].cpu(), gold["pose_enc"])
+    de = common.max_rel(out["depth"][0, :, ::37, ::37, 0].cpu(), gold["depth"])
+    print("%s vs f32 reference: tokens %s pose_enc %.2e depth %.2e" % (dtype, {k: "%.2e" % v for k, v in errs.items()}, pe, de))
+    assert all(torch.isfinite(t).all() for t in toks)
+    assert max(errs.values()) <= tok_tol
+    assert pe <= tok_tol and de <= tok_tol
+    del m
+    torch.cuda.empty_cache()
+
+
+def test_view_permutation_equivariance_at_bench_size():
+    """Size-independent property at the S=8 bench configuration (bf16): permuting views 1..S-1
+    permutes the aggregator outputs (view 0 keeps the slot-0 special tokens, aggregator.py:343-366).
+    Exact in real arithmetic; in bf16 only the softmax key order changes."""
+    sd = common.reduced_state_dict(2, 1)
+    m = build(sd, 2, 1, torch.bfloat16)
+    S = 8
+    inp = common.inputs_for(S, DEV)
+    perm = [0, 5, 3, 7, 1, 6, 2, 4]
+    with torch.no_grad():
+        a, _ = m.aggregator(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], [2, 5], [0, 3])
+        pi = {k: v[:, perm].contiguous() for k, v in inp.items()}
+        dgi = [perm.index(2), perm.index(5)]
+        cgi = [0, perm.index(3)]
+        b, _ = m.aggregator(pi["images"], pi["extrinsics"], pi["intrinsics"], pi["depth"], pi["mask"], sorted(dgi), cgi)
+    for l in range(2):
+        assert torch.isfinite(a[l]).all()
+        assert common.max_rel(b[l].cpu(), a[l][:, perm].cpu()) <= 3e-2
+
+
+def test_rejects_bad_inputs():
+    sd = common.reduced_state_dict(1, 1)
+    m = build(sd, 1, 1, torch.bfloat16)
+    with pytest.raises(ValueError):
+        m.aggregator(torch.zeros(1, 2, 4, 518, 518, device=DEV), None, None, None, None, [], [])
+    with pytest.raises(NotImplementedError):
+        m.aggregator(torch.zeros(1, 2, 3, 392, 518, device=DEV), None, None, None, None, [], [])
+    with pytest.raises(L.OvgError):
+        m.aggregator(torch.zeros(1, 2, 3, 518, 518), None, None, None, None, [], [])

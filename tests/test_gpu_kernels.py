@@ -1,0 +1,63 @@
+"""-m gpu: every HIP kernel, called through the C ABI, against a PyTorch CPU fp32 evaluation
+of the same op on the same dtype-rounded inputs (tolerances in gpu_selftest.TOL: bf16 2e-2,
+f16 4e-3, f32 2e-5 max-rel; f32 GEMM/attention additionally <= 5e-5 through a whole block)."""
+import pytest
+import torch
+
+import gpu_selftest as st
+from omnivggt_official_amd import lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _need_gpu():
+    L.require_gpu()
+    st.results.clear()
+
+
+def _assert_clean():
+    bad = [r for r in st.results if not r["ok"]]
+    assert st.results and not bad, bad
+
+
+def test_mfma_lane_maps():
+    st.test_probe()
+    _assert_clean()
+
+
+def test_layernorm():
+    st.test_layernorm()
+    _assert_clean()
+
+
+def test_linear_epilogues():
+    st.test_linear(False)
+    _assert_clean()
+
+
+def test_qkv_qknorm_rope():
+    st.test_qkv(False)
+    _assert_clean()
+
+
+def test_flash_attention_incl_ragged_segments_and_rescale():
+    st.test_attn(False)
+    _assert_clean()
+
+
+def test_embed_kernels():
+    st.test_embed()
+    _assert_clean()
+
+
+def test_block_forward():
+    st.test_block(False)
+    _assert_clean()
+
+
+def test_loaded_library_is_the_in_tree_one():
+    import os
+    assert os.path.samefile(L.LIB_PATH, os.path.join(os.path.dirname(L.__file__), "libomnivggt_hip.so"))
+    maps = open("/proc/self/maps").read()
+    assert "libomnivggt_hip.so" in maps

@@ -1,0 +1,47 @@
+"""The CPU oracle against the committed golden vectors (sub-sampled outputs of the REAL
+reference, produced by oracle/gen_golden.py in the build container).  In that container the
+oracle matched the reference bit-for-bit (tests/golden/oracle_vs_reference_report.json)."""
+import json
+import os
+
+import pytest
+import torch
+
+import aggregator_oracle as orc
+import common
+
+
+def test_reference_report_says_bit_exact():
+    rep = json.load(open(os.path.join(common.GOLD, "oracle_vs_reference_report.json")))
+    assert set(rep) == set(common.CASES)
+    for case in rep.values():
+        assert max(case["oracle_vs_reference_max_rel"].values()) <= 2e-5
+
+
+@pytest.mark.parametrize("name", ["s2_images_only", "s3_partial_aux", "s2_full_aux"])
+def test_oracle_reproduces_reference_golden(name):
+    S, dgi, cgi = common.CASES[name]
+    sd = common.full_state_dict()
+    inp = orc.synthetic_inputs(S)
+    torch.set_num_threads(os.cpu_count())
+    with torch.no_grad():
+        out = orc.model_forward(sd, inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
+    gold = common.load_golden(name)
+    # same torch build + same thread-independent kernels => bit-exact here; leave slack for other hosts
+    tol = 1e-5
+    for l in common.TOK_LAYERS:
+        assert common.max_rel(common.sample_tokens(out["_tokens"], l), gold["tok_L%d" % l]) <= tol
+    assert common.max_rel(out["pose_enc"], gold["pose_enc"]) <= tol
+    assert common.max_rel(out["depth"][0, :, ::37, ::37, 0], gold["depth"]) <= tol
+    assert common.max_rel(out["world_points"][0, :, ::37, ::37], gold["world_points"]) <= tol
+    assert common.max_rel(out["depth_conf"][0, :, ::37, ::37], gold["depth_conf"]) <= tol
+    absmean = [float(t.abs().mean()) for t in out["_tokens"]]
+    assert common.max_rel(torch.tensor(absmean), gold["tok_absmean"]) <= tol
+
+
+def test_sensitised_weights_make_the_trunk_visible():
+    """with sensitised weights the AA blocks change the tokens substantially,
+    so a wrong kernel cannot hide behind LayerScale=0.01."""
+    gold = common.load_golden("s2_full_aux")
+    am = gold["tok_absmean"]
+    assert am[-1] > 1.2 * am[0] or am[-1] < 0.8 * am[0] or abs(am[12] - am[0]) > 0.1 * am[0]

@@ -1,0 +1,140 @@
+"""World-size-2 CPU (gloo) run of the view-sharded control flow
+(omnivggt-official_amd/sharding.py) with an ORACLE-backed executor in place of the HIP one:
+validates the partition, the K/V^T all-gather plumbing (uneven shards, padded buffers,
+per-segment valid counts, rank-ordered segments), the camera-token gather and the gathered
+output -- against the monolithic oracle.  Test infrastructure only: the product executor
+(HipExecutor) has no CPU path."""
+import math
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+import aggregator_oracle as orc
+import common
+from omnivggt_official_amd import sharding
+
+DEPTH, DINO = 2, 1
+LOG2E = 1.4426950408889634
+
+
+class OracleExecutor:
+    """Same interface as sharding.HipExecutor, numerics by the CPU oracle (fp32)."""
+
+    def __init__(self, sd, depth):
+        self.sd, self.depth = sd, depth
+
+    def embed(self, inputs, view_slice):
+        st = orc.aggregator_prepare(self.sd, *inputs, dino_layers=DINO)
+        self.st = st
+        lo, hi = view_slice
+        self.lo, self.hi = lo, hi
+        tables = [orc.camera_injection(self.sd, i, st).reshape(st["K"], -1) for i in range(self.depth + 1)]
+        return st["tokens"][lo:hi].reshape(-1, 1024).clone(), tables
+
+    def new_outputs(self, n_local, P):
+        return [torch.zeros(1, n_local, P, 2048) for _ in range(self.depth)]
+
+    def workspaces(self, n_local, max_local, P):
+        pad = (max_local * P + 63) // 64 * 64
+        ws = type("WS", (), {})()
+        ws.n, ws.P = n_local, P
+        ws.q = torch.zeros(16, pad, 64)
+        ws.k = torch.zeros(16, pad, 64)
+        ws.vt = torch.zeros(16, 64, pad)
+        return ws, ws
+
+    def gather_buffers(self, ws, world):
+        return torch.zeros((world,) + tuple(ws.k.shape)), torch.zeros((world,) + tuple(ws.vt.shape))
+
+    def frame_block(self, i, ws, x_in, x_out, inject, P):
+        n = x_in.shape[0] // P
+        pos = self.st["pos"][self.lo:self.hi]
+        y = orc.block(x_in.reshape(n, P, 1024), self.sd, "aggregator.frame_blocks.%d" % i, pos, self.st["rope"], True)
+        y = y.clone()
+        y[:, 0] += inject
+        x_out.copy_(y.reshape(-1, 1024))
+
+    def _qkv(self, i, x_in):
+        pre = "aggregator.global_blocks.%d" % i
+        n = x_in.shape[0]
+        xn = orc.layer_norm(x_in, self.sd, pre + ".norm1", 1e-5)
+        qkv = F.linear(xn, self.sd[pre + ".attn.qkv.weight"], self.sd[pre + ".attn.qkv.bias"]).reshape(1, n, 3, 16, 64).permute(2, 0, 3, 1, 4)
+        q = orc.layer_norm(qkv[0], self.sd, pre + ".attn.q_norm", 1e-5)
+        k = orc.layer_norm(qkv[1], self.sd, pre + ".attn.k_norm", 1e-5)
+        pos = self.st["pos"][self.lo:self.hi].reshape(1, n, 2)
+        q = orc.rope_2d(q, pos, *self.st["rope"])
+        k = orc.rope_2d(k, pos, *self.st["rope"])
+        return q[0] * (0.125 * LOG2E), k[0], qkv[2][0]
+
+    def global_kv(self, i, ws, x_in, x_out):
+        q, k, v = self._qkv(i, x_in.contiguous())
+        n = k.shape[1]
+        ws.k.zero_()
+        ws.vt.zero_()
+        ws.k[:, :n] = k
+        ws.vt[:, :, :n] = v.transpose(1, 2)
+        self._q = q
+        return ws.k, ws.vt
+
+    def global_q(self, i, ws, x_in, x_out):
+        ws.q[:, : self._q.shape[1]] = self._q
+
+    def global_rest(self, i, ws, x_in, x_out, kg, vg, counts, rank):
+        pre = "aggregator.global_blocks.%d" % i
+        n = x_in.shape[0]
+        keys = torch.cat([kg[r][:, :c] for r, c in enumerate(counts)], dim=1)          # rank order
+        vals = torch.cat([vg[r][:, :, :c].transpose(1, 2) for r, c in enumerate(counts)], dim=1)
+        assert torch.equal(kg[rank], ws.k) and torch.equal(vg[rank], ws.vt)
+        s = (ws.q[:, :n] @ keys.transpose(1, 2)) * math.log(2.0)
+        o = (torch.softmax(s, dim=-1) @ vals).permute(1, 0, 2).reshape(n, 1024)
+        x = x_in + F.linear(o, self.sd[pre + ".attn.proj.weight"], self.sd[pre + ".attn.proj.bias"]) * self.sd[pre + ".ls1.gamma"]
+        m = orc.mlp(orc.layer_norm(x, self.sd, pre + ".norm2", 1e-5), self.sd, pre + ".mlp")
+        x_out.copy_(x + m * self.sd[pre + ".ls2.gamma"])
+
+
+class FakeAgg:
+    depth, tokens_per_view, patch_start_idx = DEPTH, 1374, 5
+
+
+def _worker(rank, world, port, S, dgi, cgi, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sd = common.reduced_state_dict(DEPTH, DINO)
+        inp = orc.synthetic_inputs(S)
+        sh = sharding.ViewSharding(executor_factory=lambda agg, dev: OracleExecutor(sd, DEPTH), gather_output=True)
+        outs, start = sh.forward(FakeAgg(), inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
+        assert start == 5 and sh.last_partition == sharding.partition(S, world)
+        if rank == 0:
+            torch.save([o.clone() for o in outs], os.path.join(result_dir, "sharded.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("S,dgi,cgi", [(3, [1], [0, 2])])
+def test_view_sharded_forward_matches_monolithic_oracle(tmp_path, S, dgi, cgi):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), S, dgi, cgi, str(tmp_path)), nprocs=world, join=True)
+    sharded = torch.load(os.path.join(str(tmp_path), "sharded.pt"))
+    sd = common.reduced_state_dict(DEPTH, DINO)
+    inp = orc.synthetic_inputs(S)
+    with torch.no_grad():
+        ref, _ = orc.aggregator_forward(sd, inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi,
+                                        depth_layers=DEPTH, dino_layers=DINO)
+    assert len(sharded) == DEPTH
+    for a, b in zip(sharded, ref):
+        assert a.shape == b.shape == (1, S, 1374, 2048)
+        assert common.max_rel(a, b) < 2e-5
