@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--views", type=int, default=0, help="total views S (default 8 per GPU)")
     ap.add_argument("--dtype", default="bf16", choices=list(DT))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--e2e", action="store_true", help="also time OmniVGGT.forward incl. the PyTorch heads (MIOpen JIT makes the first call slow)")
     ap.add_argument("--attn-variant", type=int, default=0)
     args = ap.parse_args()
 
@@ -156,7 +156,7 @@ def main():
                 result["roofline"]["traffic"] = json.load(open(tr)).get("global_attn_S%d_bytes_per_launch" % S)
             except Exception:
                 pass
-        if not args.no_e2e:
+        if args.e2e:
             try:
                 full = lambda: model(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], [], [])
                 full()

@@ -95,4 +95,8 @@ OVG_DEV int xcd_remap(int b, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// hipGetLastError() is per-thread and sticky until read: the host framework's own benign failures
+// (hipEventQuery -> NotReady, hipPointerGetAttributes on pageable memory, ...) must not be mistaken
+// for a failed launch of ours, so the slot is drained immediately before every launch.
+#define OVG_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 #define OVG_CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return OVG_E_LAUNCH; } while (0)

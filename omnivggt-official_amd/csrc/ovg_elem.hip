@@ -210,11 +210,11 @@ extern "C" int ovg_layernorm(const ovg_layernorm_params* p, void* stream) {
   if (!al16(p->x) || !al16(p->y) || !al16(p->weight) || !al16(p->bias) || (p->ldx % 4) || (p->ldy % 4)) return OVG_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(grid_for(p->rows, 4)), block(256);
-  if (p->out_f32) hipLaunchKernelGGL((layernorm_kernel<float, true>), grid, block, 0, st, *p);
+  if (p->out_f32) OVG_LAUNCH((layernorm_kernel<float, true>), grid, block, 0, st, *p);
   else switch (p->dtype) {
-    case OVG_BF16: hipLaunchKernelGGL((layernorm_kernel<bf16_t, false>), grid, block, 0, st, *p); break;
-    case OVG_F16: hipLaunchKernelGGL((layernorm_kernel<f16_t, false>), grid, block, 0, st, *p); break;
-    case OVG_F32: hipLaunchKernelGGL((layernorm_kernel<float, true>), grid, block, 0, st, *p); break;
+    case OVG_BF16: OVG_LAUNCH((layernorm_kernel<bf16_t, false>), grid, block, 0, st, *p); break;
+    case OVG_F16: OVG_LAUNCH((layernorm_kernel<f16_t, false>), grid, block, 0, st, *p); break;
+    case OVG_F32: OVG_LAUNCH((layernorm_kernel<float, true>), grid, block, 0, st, *p); break;
     default: return OVG_E_DTYPE;
   }
   OVG_CHECK_LAUNCH();
@@ -231,9 +231,9 @@ extern "C" int ovg_im2col(const ovg_im2col_params* p, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(grid_for(total, 256, 65536)), block(256);
   switch (p->dtype) {
-    case OVG_BF16: hipLaunchKernelGGL((im2col_kernel<bf16_t>), grid, block, 0, st, *p, gh, gw, total); break;
-    case OVG_F16: hipLaunchKernelGGL((im2col_kernel<f16_t>), grid, block, 0, st, *p, gh, gw, total); break;
-    case OVG_F32: hipLaunchKernelGGL((im2col_kernel<float>), grid, block, 0, st, *p, gh, gw, total); break;
+    case OVG_BF16: OVG_LAUNCH((im2col_kernel<bf16_t>), grid, block, 0, st, *p, gh, gw, total); break;
+    case OVG_F16: OVG_LAUNCH((im2col_kernel<f16_t>), grid, block, 0, st, *p, gh, gw, total); break;
+    case OVG_F32: OVG_LAUNCH((im2col_kernel<float>), grid, block, 0, st, *p, gh, gw, total); break;
     default: return OVG_E_DTYPE;
   }
   OVG_CHECK_LAUNCH();
@@ -243,16 +243,16 @@ extern "C" int ovg_im2col(const ovg_im2col_params* p, void* stream) {
 extern "C" int ovg_depth_stats(const ovg_depth_stats_params* p, void* stream) {
   if (!p || !p->depth || !p->mask || !p->stats || !p->partial || p->B <= 0 || p->n_per_batch <= 0 || p->nblocks <= 0) return OVG_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(depth_stats_stage1, dim3(p->nblocks, (unsigned)p->B), dim3(256), 0, st, *p);
+  OVG_LAUNCH(depth_stats_stage1, dim3(p->nblocks, (unsigned)p->B), dim3(256), 0, st, *p);
   OVG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(depth_stats_stage2, dim3((unsigned)p->B), dim3(64), 0, st, *p);
+  OVG_LAUNCH(depth_stats_stage2, dim3((unsigned)p->B), dim3(64), 0, st, *p);
   OVG_CHECK_LAUNCH();
   return OVG_OK;
 }
 
 extern "C" int ovg_dino_specials(const ovg_dino_specials_params* p, void* stream) {
   if (!p || !p->x || !p->cls || !p->pos0 || (p->n_reg > 0 && !p->reg) || p->V <= 0 || (p->ldx % 4)) return OVG_E_ARG;
-  hipLaunchKernelGGL(dino_specials_kernel, dim3((unsigned)(p->V * (1 + p->n_reg))), dim3(256), 0, static_cast<hipStream_t>(stream), *p);
+  OVG_LAUNCH(dino_specials_kernel, dim3((unsigned)(p->V * (1 + p->n_reg))), dim3(256), 0, static_cast<hipStream_t>(stream), *p);
   OVG_CHECK_LAUNCH();
   return OVG_OK;
 }
@@ -261,14 +261,14 @@ extern "C" int ovg_assemble_tokens(const ovg_assemble_params* p, void* stream) {
   if (!p || !p->xd || !p->norm_w || !p->norm_b || !p->camera_token || !p->register_token || !p->cam_add || !p->placeholder || !p->out)
     return OVG_E_ARG;
   if (p->V <= 0 || p->S <= 0 || p->view0 < 0 || p->tokens_per_view <= p->n_special || (p->ldo % 4) || (p->ldxd % 4)) return OVG_E_ARG;
-  hipLaunchKernelGGL(assemble_kernel, dim3(grid_for(p->V * p->tokens_per_view, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), *p);
+  OVG_LAUNCH(assemble_kernel, dim3(grid_for(p->V * p->tokens_per_view, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), *p);
   OVG_CHECK_LAUNCH();
   return OVG_OK;
 }
 
 extern "C" int ovg_copy_rows(const ovg_copy_rows_params* p, void* stream) {
   if (!p || !p->x || !p->y || p->rows <= 0 || p->n <= 0 || (p->n % 4) || (p->ldx % 4) || (p->ldy % 4)) return OVG_E_ARG;
-  hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(p->rows * (p->n / 4), 256)), dim3(256), 0, static_cast<hipStream_t>(stream), *p);
+  OVG_LAUNCH(copy_rows_kernel, dim3(grid_for(p->rows * (p->n / 4), 256)), dim3(256), 0, static_cast<hipStream_t>(stream), *p);
   OVG_CHECK_LAUNCH();
   return OVG_OK;
 }
@@ -280,9 +280,9 @@ extern "C" int ovg_probe_mfma(const void* a, const void* b, float* out, int dtyp
   const u32x4* B = static_cast<const u32x4*>(b);
   f32x4* O = reinterpret_cast<f32x4*>(out);
   switch (dtype) {
-    case OVG_BF16: hipLaunchKernelGGL((probe_kernel<bf16_t>), dim3(1), dim3(64), 0, st, A, B, O); break;
-    case OVG_F16: hipLaunchKernelGGL((probe_kernel<f16_t>), dim3(1), dim3(64), 0, st, A, B, O); break;
-    case OVG_F32: hipLaunchKernelGGL((probe_kernel<float>), dim3(1), dim3(64), 0, st, A, B, O); break;
+    case OVG_BF16: OVG_LAUNCH((probe_kernel<bf16_t>), dim3(1), dim3(64), 0, st, A, B, O); break;
+    case OVG_F16: OVG_LAUNCH((probe_kernel<f16_t>), dim3(1), dim3(64), 0, st, A, B, O); break;
+    case OVG_F32: OVG_LAUNCH((probe_kernel<float>), dim3(1), dim3(64), 0, st, A, B, O); break;
     default: return OVG_E_DTYPE;
   }
   OVG_CHECK_LAUNCH();

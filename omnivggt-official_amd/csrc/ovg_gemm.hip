@@ -267,17 +267,17 @@ int launch_linear(const ovg_linear_params& p, hipStream_t st) {
   const dim3 grid(mt * nt), block(256);
   switch (p.epilogue) {
     case OVG_EPI_STORE:
-      if (p.out_f32) hipLaunchKernelGGL((linear_kernel<T, OVG_EPI_STORE, true>), grid, block, 0, st, p, nt);
-      else hipLaunchKernelGGL((linear_kernel<T, OVG_EPI_STORE, false>), grid, block, 0, st, p, nt);
+      if (p.out_f32) OVG_LAUNCH((linear_kernel<T, OVG_EPI_STORE, true>), grid, block, 0, st, p, nt);
+      else OVG_LAUNCH((linear_kernel<T, OVG_EPI_STORE, false>), grid, block, 0, st, p, nt);
       break;
     case OVG_EPI_GELU:
-      hipLaunchKernelGGL((linear_kernel<T, OVG_EPI_GELU, false>), grid, block, 0, st, p, nt);
+      OVG_LAUNCH((linear_kernel<T, OVG_EPI_GELU, false>), grid, block, 0, st, p, nt);
       break;
     case OVG_EPI_RES:
-      hipLaunchKernelGGL((linear_kernel<T, OVG_EPI_RES, true>), grid, block, 0, st, p, nt);
+      OVG_LAUNCH((linear_kernel<T, OVG_EPI_RES, true>), grid, block, 0, st, p, nt);
       break;
     case OVG_EPI_PATCH:
-      hipLaunchKernelGGL((linear_kernel<T, OVG_EPI_PATCH, true>), grid, block, 0, st, p, nt);
+      OVG_LAUNCH((linear_kernel<T, OVG_EPI_PATCH, true>), grid, block, 0, st, p, nt);
       break;
     default: return OVG_E_ARG;
   }
@@ -331,9 +331,9 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
   const dim3 grid((unsigned)(((p->M + BM - 1) / BM) * nt_count)), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (p->dtype) {
-    case OVG_BF16: hipLaunchKernelGGL((qkv_kernel<bf16_t>), grid, block, 0, st, *p, nt_begin, nt_count); break;
-    case OVG_F16: hipLaunchKernelGGL((qkv_kernel<f16_t>), grid, block, 0, st, *p, nt_begin, nt_count); break;
-    case OVG_F32: hipLaunchKernelGGL((qkv_kernel<float>), grid, block, 0, st, *p, nt_begin, nt_count); break;
+    case OVG_BF16: OVG_LAUNCH((qkv_kernel<bf16_t>), grid, block, 0, st, *p, nt_begin, nt_count); break;
+    case OVG_F16: OVG_LAUNCH((qkv_kernel<f16_t>), grid, block, 0, st, *p, nt_begin, nt_count); break;
+    case OVG_F32: OVG_LAUNCH((qkv_kernel<float>), grid, block, 0, st, *p, nt_begin, nt_count); break;
     default: return OVG_E_DTYPE;
   }
   OVG_CHECK_LAUNCH();

@@ -205,13 +205,12 @@ def attn_reference(q, k, v):
 def test_attn(quick):
     g = torch.Generator().manual_seed(5)
     for name, dt in DT.items():
-        cases = [("n1374_bh32", 32, 1374, [1374], 0), ("n2748_2seg", 16, 2748 // 2, [1374, 1374], 0),
-                 ("n700_ragged_seg", 16, 700, [100, 333, 64], 0)]
-        if name != "f32":
-            cases += [("n1374_bh16_qb2", 16, 1374, [1374], 2), ("n300_qb2_seg", 16, 300, [130, 70], 2)]
+        shapes = [("n1374_bh32", 32, 1374, [1374]), ("n2748_2seg", 16, 2748 // 2, [1374, 1374]),
+                  ("n700_ragged_seg", 16, 700, [100, 333, 64]), ("n300_seg", 16, 300, [130, 70])]
+        variants = (1,) if name == "f32" else (1, 2, 3, 4, 5)      # baseline QB=1/2, tuned QB=2/4/3
         if quick:
-            cases = cases[:2]
-        for cname, BH, nq, nks, variant in cases:
+            shapes = shapes[:2]
+        for cname, BH, nq, nks in shapes:
             q = (rnd(BH, nq, 64, g=g) * 1.2).to(dt)
             ks = [(rnd(BH, nk, 64, g=g)).to(dt) for nk in nks]
             vs = [(rnd(BH, nk, 64, g=g)).to(dt) for nk in nks]
@@ -226,21 +225,28 @@ def test_attn(quick):
                 kd[:, :nk] = kk.to(DEV)
                 vtd[:, :, :nk] = vv.transpose(1, 2).to(DEV)
                 segs.append((kd, vtd, nk))
-            out = ops.flash_attn(qd, segs, nq, dt, variant=variant)
-            report("attn_%s_%s" % (name, cname), out, ref_tok, TOL[name])
-        # forced-rescale case: one key spikes against one query late in the sequence
-        BH, nq, nk = 16, 128, 640
-        q = rnd(BH, nq, 64, g=g).to(dt)
-        k = rnd(BH, nk, 64, g=g).to(dt)
-        v = rnd(BH, nk, 64, g=g).to(dt)
-        k[:, 500] = (q[:, 7].float() * 6).to(dt)
-        ref = attn_reference(q.float(), k.float(), v.float()).reshape(1, 16, nq, 64).permute(0, 2, 1, 3).reshape(-1, 1024)
-        qd, kd, vtd = ops.alloc_qkv(BH, nq, nk, dt, DEV)
-        qd[:, :nq] = q.to(DEV)
-        kd[:, :nk] = k.to(DEV)
-        vtd[:, :, :nk] = v.transpose(1, 2).to(DEV)
-        out = ops.flash_attn(qd, [(kd, vtd, nk)], nq, dt)
-        report("attn_%s_spike_rescale" % name, out, ref, TOL[name])
+            for variant in variants:
+                out = ops.flash_attn(qd, segs, nq, dt, variant=variant)
+                report("attn_%s_%s_v%d" % (name, cname, variant), out, ref_tok, TOL[name])
+        # forced-rescale cases: one key spikes against one query late in the sequence (the lazy
+        # rescale branch of the tuned kernel fires mid-stream), and a slowly rising score ramp
+        for cname, spike in (("spike", 6.0), ("ramp", 0.0)):
+            BH, nq, nk = 16, 128, 640
+            q = rnd(BH, nq, 64, g=g).to(dt)
+            k = rnd(BH, nk, 64, g=g).to(dt)
+            v = rnd(BH, nk, 64, g=g).to(dt)
+            if spike:
+                k[:, 500] = (q[:, 7].float() * spike).to(dt)
+            else:
+                k = (k.float() + q[:, 3:4].float() * torch.linspace(0, 3, nk).view(1, nk, 1)).to(dt)
+            ref = attn_reference(q.float(), k.float(), v.float()).reshape(1, 16, nq, 64).permute(0, 2, 1, 3).reshape(-1, 1024)
+            qd, kd, vtd = ops.alloc_qkv(BH, nq, nk, dt, DEV)
+            qd[:, :nq] = q.to(DEV)
+            kd[:, :nk] = k.to(DEV)
+            vtd[:, :, :nk] = v.transpose(1, 2).to(DEV)
+            for variant in ((1,) if name == "f32" else (1, 3, 4, 5)):
+                out = ops.flash_attn(qd, [(kd, vtd, nk)], nq, dt, variant=variant)
+                report("attn_%s_%s_rescale_v%d" % (name, cname, variant), out, ref, TOL[name])
 
 
 def test_embed():
@@ -363,7 +369,7 @@ def microbench():
             print("gemm %-10s S=%d M=%d N=%d K=%d: %.3f ms  %.1f TFLOP/s" % (nm, S, M, N, K, ms, tf), flush=True)
             out["gemm_%s_S%d" % (nm, S)] = {"ms": ms, "tflops": tf}
         # global attention
-        for variant in (1, 2):
+        for variant in (1, 2, 3, 4, 5):
             BH, n = 16, M
             q, k, vt = ops.alloc_qkv(BH, n, n, dt, DEV)
             q[:, :n] = rnd(BH, n, 64, g=g).to(dt).to(DEV)
@@ -375,7 +381,7 @@ def microbench():
             print("global attn S=%d N=%d variant(QB)=%d: %.3f ms  %.1f TFLOP/s (%.1f%% of 2.5 PF)" % (S, n, variant, ms, tf, tf / 25.0), flush=True)
             out["gattn_S%d_qb%d" % (S, variant)] = {"ms": ms, "tflops": tf}
         # frame attention
-        for variant in (1, 2):
+        for variant in (1, 2, 3, 4, 5):
             BH, n = S * 16, 1374
             q, k, vt = ops.alloc_qkv(BH, n, n, dt, DEV)
             q[:, :n] = rnd(BH, n, 64, g=g).to(dt).to(DEV)

@@ -3,9 +3,10 @@ golden vectors of the real reference.
 
 Tolerances (max|a-b| / max|b| per tensor):
   f32 parity mode : <= 1e-4 on every aggregator layer and on pose_enc / depth / points
-  bf16 / f16 modes: reported next to the f32 oracle; gated loosely (tokens <= 0.2 / 0.05) because
+  bf16 / f16 modes: reported next to the f32 reference; gated loosely (tokens <= 0.2 / 0.05) because
                     with the sensitised weights the reference itself moves 7e-2..1e-1 under
                     torch.autocast(bf16) -- the 1e-4 target is an fp32 statement.
+Heads are stock PyTorch (out of kernel scope) and are exercised in two tests only.
 """
 import os
 
@@ -36,12 +37,16 @@ def build(sd, depth, dino_depth, dtype):
     return m.to(DEV).eval()
 
 
-def run_model(m, S, dgi, cgi):
+def run_agg(m, S, dgi, cgi):
     inp = common.inputs_for(S, DEV)
     with torch.no_grad():
-        toks, start = m.aggregator(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
-        out = m(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
-    return toks, start, out
+        return m.aggregator(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
+
+
+def run_full(m, S, dgi, cgi):
+    inp = common.inputs_for(S, DEV)
+    with torch.no_grad():
+        return m(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
 
 
 @pytest.fixture(scope="module")
@@ -52,34 +57,46 @@ def reduced():
 
 @pytest.mark.parametrize("S,dgi,cgi", [(2, [], []), (2, [1], []), (3, [], [0, 2]), (3, [1], [0, 2]), (2, [0, 1], [0, 1])])
 def test_f32_parity_all_modality_combos_depth2(reduced, S, dgi, cgi):
-    """depth-2 / DINO-2 model, every modality combination incl. partial / interleaved indices."""
+    """depth-2 / DINO-2 aggregator, every modality combination incl. partial / interleaved indices."""
     sd, m = reduced
+    inp = orc.synthetic_inputs(S)
+    with torch.no_grad():
+        ref, _ = orc.aggregator_forward(sd, inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi,
+                                        depth_layers=2, dino_layers=2)
+    toks, start = run_agg(m, S, dgi, cgi)
+    assert start == 5 and len(toks) == 2
+    for l in range(2):
+        assert toks[l].shape == (1, S, 1374, 2048) and toks[l].dtype == torch.float32
+        assert common.max_rel(toks[l].cpu(), ref[l]) <= F32_TOL
+
+
+def test_f32_end_to_end_dict_depth2(reduced):
+    """OmniVGGT.forward contract (keys, shapes, values) with the PyTorch heads, vs the oracle."""
+    sd, m = reduced
+    S, dgi, cgi = 2, [0], [0, 1]
     inp = orc.synthetic_inputs(S)
     with torch.no_grad():
         ref = orc.model_forward(sd, inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi,
                                 depth_layers=2, dino_layers=2)
-    toks, start, out = run_model(m, S, dgi, cgi)
-    assert start == 5 and len(toks) == 2
-    for l in range(2):
-        assert toks[l].shape == (1, S, 1374, 2048) and toks[l].dtype == torch.float32
-        assert common.max_rel(toks[l].cpu(), ref["_tokens"][l]) <= F32_TOL
+    out = run_full(m, S, dgi, cgi)
+    assert set(out) == {"pose_enc", "pose_enc_list", "depth", "depth_conf", "world_points", "world_points_conf", "images"}
     for key in ("pose_enc", "depth", "depth_conf", "world_points", "world_points_conf"):
-        assert out[key].shape == ref[key].shape
+        assert out[key].shape == ref[key].shape and out[key].dtype == torch.float32
         assert common.max_rel(out[key].cpu(), ref[key]) <= F32_TOL, key
     assert len(out["pose_enc_list"]) == 4 and out["images"].shape == (1, S, 3, 518, 518)
 
 
 @pytest.fixture(scope="module")
-def full_f32():
-    sd = common.full_state_dict()
-    return build(sd, 24, 24, torch.float32)
+def full_model():
+    return build(common.full_state_dict(), 24, 24, torch.float32)
 
 
 @pytest.mark.parametrize("name", ["s2_images_only", "s3_partial_aux", "s2_full_aux"])
-def test_f32_full_depth_vs_reference_golden(full_f32, name):
-    """Full 24+24+24-block model in f32 parity mode against the REAL reference's outputs."""
+def test_f32_full_depth_vs_reference_golden(full_model, name):
+    """Full 24+24+24-block aggregator in f32 parity mode against the REAL reference's tokens."""
+    full_model.set_compute_dtype(torch.float32)
     S, dgi, cgi = common.CASES[name]
-    toks, start, out = run_model(full_f32, S, dgi, cgi)
+    toks, start = run_agg(full_model, S, dgi, cgi)
     gold = common.load_golden(name)
     worst = 0.0
     for l in common.TOK_LAYERS:
@@ -88,29 +105,30 @@ def test_f32_full_depth_vs_reference_golden(full_f32, name):
         assert e <= F32_TOL, (l, e)
     absmean = torch.tensor([float(t.abs().mean()) for t in toks])
     assert common.max_rel(absmean, gold["tok_absmean"]) <= F32_TOL
+    print("f32 full-depth %s: worst sampled token max-rel %.2e" % (name, worst))
+
+
+def test_f32_full_depth_predictions_vs_reference_golden(full_model):
+    full_model.set_compute_dtype(torch.float32)
+    S, dgi, cgi = common.CASES["s3_partial_aux"]
+    out = run_full(full_model, S, dgi, cgi)
+    gold = common.load_golden("s3_partial_aux")
     assert common.max_rel(out["pose_enc"].cpu(), gold["pose_enc"]) <= F32_TOL
     assert common.max_rel(out["depth"][0, :, ::37, ::37, 0].cpu(), gold["depth"]) <= F32_TOL
     assert common.max_rel(out["depth_conf"][0, :, ::37, ::37].cpu(), gold["depth_conf"]) <= F32_TOL
     assert common.max_rel(out["world_points"][0, :, ::37, ::37].cpu(), gold["world_points"]) <= F32_TOL
-    print("f32 full-depth %s: worst sampled token max-rel %.2e" % (name, worst))
 
 
 @pytest.mark.parametrize("dtype,tok_tol", [(torch.bfloat16, 0.2), (torch.float16, 0.05)])
-def test_low_precision_modes_vs_golden(dtype, tok_tol):
-    sd = common.full_state_dict()
-    m = build(sd, 24, 24, dtype)
+def test_low_precision_modes_vs_golden(full_model, dtype, tok_tol):
+    full_model.set_compute_dtype(dtype)
     S, dgi, cgi = common.CASES["s3_partial_aux"]
-    toks, start, out = run_model(m, S, dgi, cgi)
+    toks, start = run_agg(full_model, S, dgi, cgi)
     gold = common.load_golden("s3_partial_aux")
     errs = {l: common.max_rel(common.sample_tokens([t.cpu() for t in toks], l), gold["tok_L%d" % l]) for l in common.TOK_LAYERS}
-    pe = common.max_rel(out["pose_enc"].cpu(), gold["pose_enc"])
-    de = common.max_rel(out["depth"][0, :, ::37, ::37, 0].cpu(), gold["depth"])
-    print("%s vs f32 reference: tokens %s pose_enc %.2e depth %.2e" % (dtype, {k: "%.2e" % v for k, v in errs.items()}, pe, de))
+    print("%s vs f32 reference tokens (max-rel): %s" % (dtype, {k: "%.2e" % v for k, v in errs.items()}))
     assert all(torch.isfinite(t).all() for t in toks)
     assert max(errs.values()) <= tok_tol
-    assert pe <= tok_tol and de <= tok_tol
-    del m
-    torch.cuda.empty_cache()
 
 
 def test_view_permutation_equivariance_at_bench_size():
@@ -125,9 +143,9 @@ def test_view_permutation_equivariance_at_bench_size():
     with torch.no_grad():
         a, _ = m.aggregator(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], [2, 5], [0, 3])
         pi = {k: v[:, perm].contiguous() for k, v in inp.items()}
-        dgi = [perm.index(2), perm.index(5)]
+        dgi = sorted([perm.index(2), perm.index(5)])
         cgi = [0, perm.index(3)]
-        b, _ = m.aggregator(pi["images"], pi["extrinsics"], pi["intrinsics"], pi["depth"], pi["mask"], sorted(dgi), cgi)
+        b, _ = m.aggregator(pi["images"], pi["extrinsics"], pi["intrinsics"], pi["depth"], pi["mask"], dgi, cgi)
     for l in range(2):
         assert torch.isfinite(a[l]).all()
         assert common.max_rel(b[l].cpu(), a[l][:, perm].cpu()) <= 3e-2
