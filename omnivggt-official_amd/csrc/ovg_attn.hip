@@ -262,17 +262,34 @@ __global__ __launch_bounds__(256) void attn_kernel(ovg_attn_params p, int nqt, i
 // ---------------------------------------------------------------------------
 constexpr float RESCALE_THR = 8.0f;   // log2 units: p <= 256
 
-OVG_DEV float xl_max4(float v) {   // max over lanes {l, l^16, l^32, l^48}
-  auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-  v = fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-  r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+// Cross-lane reductions over the 4 lanes {l, l^16, l^32, l^48} of a q row with the gfx950 swap
+// instructions (v_permlane32_swap: upper half of vdst <-> lower half of src; v_permlane16_swap:
+// odd 16-lane rows of vdst <-> even rows of src).  With the same value in both operands the two
+// results hold, per lane, the value and its partner's.
+// NOTE: extract the two results into scalars first -- __builtin_bit_cast applied directly to
+// `r[1]` (a vector-element lvalue) reads element 0 with this hipcc (ROCm 7.2).
+OVG_DEV float swap32_partner_max(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const unsigned a = r[0], b = r[1];
+  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
 }
+OVG_DEV float swap16_partner_max(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned a = r[0], b = r[1];
+  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+OVG_DEV float xl_max4(float v) { return swap16_partner_max(swap32_partner_max(v)); }
 OVG_DEV float xl_sum4(float v) {
-  auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-  v = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
-  r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+  unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  unsigned a = r[0], b = r[1];
+  v = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+  u = __builtin_bit_cast(unsigned, v);
+  r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  a = r[0]; b = r[1];
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
 }
 
 template <typename T> OVG_DEV f32x4 mma_c(const u32x4& a, const u32x4& b, const f32x4& c);

@@ -133,6 +133,10 @@ def load(build_if_missing=True):
             raise OvgError("libomnivggt_hip.so is missing (run __graft_entry__.build()); there is no fallback path")
         from .build import build
         build()
+    # torch bundles its own libamdhip64.so.7; it MUST be in the process before our library is
+    # dlopen'ed, otherwise the loader maps /opt/rocm's copy for us and torch's copy for torch:
+    # two HIP runtimes, and our launches on torch's streams fail (OVG_E_LAUNCH).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)      # AttributeError here == ABI mismatch, fail loudly
