@@ -181,7 +181,8 @@ def cpu_baseline(sd, S=2):
     a bounded sample -- the full 24-layer aggregator on S=2 views (~10-30 s)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import aggregator_oracle as orc
-    cores = os.cpu_count() or 1
+    # intra-op threads: all cores up to 64 (on the 256-core GPU host, 256 torch threads are slower)
+    cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
     inp = orc.synthetic_inputs(S)
     with torch.no_grad():

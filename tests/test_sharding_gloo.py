@@ -104,7 +104,7 @@ class FakeAgg:
 def _worker(rank, world, port, S, dgi, cgi, result_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.set_num_threads(max(1, (os.cpu_count() or 2) // world))
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 2) // world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         sd = common.reduced_state_dict(DEPTH, DINO)
