@@ -500,7 +500,22 @@ int launch_attn(const ovg_attn_params& p, hipStream_t st) {
   return OVG_OK;
 }
 
-// variant: 0 = default choice, 1/2 = baseline kernel QB=1/2, 3/4/5 = tuned kernel QB=2/4/3
+#include "ovg_attn_v3.h"
+
+template <typename T, int QB, int WAVES>
+int launch_attn3(const ovg_attn_params& p, hipStream_t st) {
+  constexpr int BQ = 16 * QB * WAVES;
+  const int nqt = (int)((p.nq + BQ - 1) / BQ);
+  int total = 0;
+  for (int i = 0; i < p.nseg; ++i) total += (int)((p.seg[i].nk + BC - 1) / BC);
+  const dim3 grid((unsigned)(p.BH * nqt)), block(64 * WAVES);
+  OVG_LAUNCH((attn3_kernel<T, QB, WAVES>), grid, block, 0, st, p, nqt, total);
+  OVG_CHECK_LAUNCH();
+  return OVG_OK;
+}
+
+// variant: 0 = default choice; 1/2 = baseline kernel QB=1/2; 3/4/5 = attn2 QB=2/4/3;
+// 6..10 = attn3 (QB,WAVES) = (4,4) (4,2) (2,4) (2,2) (3,4)
 template <typename T>
 int dispatch16(const ovg_attn_params& p, hipStream_t st) {
   int v = p.variant;
@@ -511,6 +526,11 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
     case 3: return launch_attn<T, 2, true>(p, st);
     case 4: return launch_attn<T, 4, true>(p, st);
     case 5: return launch_attn<T, 3, true>(p, st);
+    case 6: return launch_attn3<T, 4, 4>(p, st);
+    case 7: return launch_attn3<T, 4, 2>(p, st);
+    case 8: return launch_attn3<T, 2, 4>(p, st);
+    case 9: return launch_attn3<T, 2, 2>(p, st);
+    case 10: return launch_attn3<T, 3, 4>(p, st);
     default: return OVG_E_ARG;
   }
 }

@@ -21,6 +21,21 @@ constexpr int BM = 128, BN = 128;
 
 OVG_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// Logical block id -> (m tile, n tile), "grouped" order: GM m-tiles x all n-tiles at a time, m fastest.
+// Each XCD works on a contiguous run of ids (xcd_remap), so the ~96 blocks resident on one XCD cover
+// GM X-tiles x ~12 W-tiles (~5 MB): both operands stay in that XCD's 4 MB L2 instead of re-streaming
+// the whole weight matrix per m-tile (measured with plain n-fastest order: 61 % L2 hit rate, 590 MB of
+// fabric reads for a 30 MB problem on fc1).
+OVG_DEV void tile_coords(int lid, int mtiles, int ntiles, int& tm, int& tn) {
+  constexpr int GM = 8;
+  const int per_group = GM * ntiles;
+  const int grp = lid / per_group, rem = lid - grp * per_group;
+  const int m_first = grp * GM;
+  const int gsz = (mtiles - m_first) < GM ? (mtiles - m_first) : GM;
+  tm = m_first + rem % gsz;
+  tn = rem / gsz;
+}
+
 // ---------------------------------------------------------------------------
 // Main loop: leaves acc[nt][mt] = C[n = n0w + 16nt + 4g + r][m = m0w + 16mt + (lane&15)]
 // ---------------------------------------------------------------------------
@@ -107,11 +122,12 @@ OVG_DEV void gemm_mainloop(const T* __restrict__ X, int64_t ldx, const T* __rest
 // Linear kernel (STORE / GELU / RES / PATCH epilogues)
 // ---------------------------------------------------------------------------
 template <typename T, int EPI, bool OUT_F32>
-__global__ __launch_bounds__(256) void linear_kernel(ovg_linear_params p, int ntiles_n) {
+__global__ __launch_bounds__(256, 2) void linear_kernel(ovg_linear_params p, int ntiles_n) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128];
   const int M = (int)p.M, N = (int)p.N, K = (int)p.K;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (bid / ntiles_n) * BM, n0 = (bid % ntiles_n) * BN;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + BM - 1) / BM, ntiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
   f32x4 acc[4][4];
   gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds, acc);
 
@@ -158,12 +174,13 @@ __global__ __launch_bounds__(256) void linear_kernel(ovg_linear_params p, int nt
 // QKV kernel: bias + per-head LayerNorm(64) + 2-D RoPE + q scale, head-major stores
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void qkv_kernel(ovg_qkv_params p, int nt_begin, int nt_count) {
+__global__ __launch_bounds__(256, 2) void qkv_kernel(ovg_qkv_params p, int nt_begin, int nt_count) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128];
   constexpr int N = 3 * OVG_C, K = OVG_C;
   const int M = (int)p.M;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (bid / nt_count) * BM, n0 = (nt_begin + bid % nt_count) * BN;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + BM - 1) / BM, nt_count, tm, tn);
+  const int m0 = tm * BM, n0 = (nt_begin + tn) * BN;
   f32x4 acc[4][4];
   gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
 
