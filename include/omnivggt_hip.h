@@ -259,6 +259,10 @@ int ovg_copy_rows(const ovg_copy_rows_params*, void* stream);
  * acc of one 16x16 MFMA for dtype given raw 16-byte A/B fragments per lane. */
 int ovg_probe_mfma(const void* a_frag, const void* b_frag, float* out, int dtype, void* stream);
 
+/* Benchmarking knob (process-global, not thread-safe, never needed for correctness):
+ * key 0 = GEMM tile-order group size (0 = n-fastest, default 8 = grouped, see ovg_gemm.hip). */
+int ovg_debug_set(int key, int value);
+
 #ifdef __cplusplus
 }
 #endif

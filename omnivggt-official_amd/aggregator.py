@@ -312,7 +312,10 @@ class ZeroAggregator(nn.Module):
         K = B * S
         G = self.depth + 1
         if len(camera_gt_index) == 0:
-            return [b.unsqueeze(0).expand(K, C).contiguous() for b in pk["adapt_b"]]
+            key = ("bias_tables", K)
+            if key not in pk:               # Linear(0) = bias for every view; constant across calls
+                pk[key] = [b.unsqueeze(0).expand(K, C).contiguous() for b in pk["adapt_b"]]
+            return pk[key]
         idx = torch.tensor(list(camera_gt_index))
         ext = torch.index_select(extrinsics.detach().float().cpu(), 1, idx)
         intr = torch.index_select(intrinsics.detach().float().cpu(), 1, idx)

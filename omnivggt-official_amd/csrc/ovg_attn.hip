@@ -519,7 +519,7 @@ int launch_attn3(const ovg_attn_params& p, hipStream_t st) {
 template <typename T>
 int dispatch16(const ovg_attn_params& p, hipStream_t st) {
   int v = p.variant;
-  if (v == 0) v = p.nq >= 4096 ? 4 : 3;
+  if (v == 0) v = p.nq >= 4096 ? 6 : 8;   // measured best: attn3 QB=4 for long sequences, QB=2 for 1374
   switch (v) {
     case 1: return launch_attn<T, 1, false>(p, st);
     case 2: return launch_attn<T, 2, false>(p, st);

@@ -19,15 +19,32 @@ namespace {
 
 constexpr int BM = 128, BN = 128;
 
-OVG_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU (nn.GELU default, mlp.py:22).  f32 parity mode calls libm's erff; the 16-bit modes
+// use Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below bf16/f16 resolution): PMC showed the
+// erff expansion (~40 VALU per element) cost as many VALU instructions as the whole fc1 main loop.
+OVG_DEV float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);
+  return copysignf(fmaf(-p * t, e, 1.0f), x);
+}
+template <typename T> OVG_DEV float gelu_erf(float x) {
+  if constexpr (sizeof(T) == 4) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  else return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
+}
 
 // Logical block id -> (m tile, n tile), "grouped" order: GM m-tiles x all n-tiles at a time, m fastest.
 // Each XCD works on a contiguous run of ids (xcd_remap), so the ~96 blocks resident on one XCD cover
 // GM X-tiles x ~12 W-tiles (~5 MB): both operands stay in that XCD's 4 MB L2 instead of re-streaming
 // the whole weight matrix per m-tile (measured with plain n-fastest order: 61 % L2 hit rate, 590 MB of
 // fabric reads for a 30 MB problem on fc1).
-OVG_DEV void tile_coords(int lid, int mtiles, int ntiles, int& tm, int& tn) {
-  constexpr int GM = 8;
+OVG_DEV void tile_coords(int lid, int mtiles, int ntiles_gm, int& tm, int& tn) {
+  const int ntiles = ntiles_gm & 0xffff, GM = ntiles_gm >> 16;   // GM == 0: plain n-fastest order
+  if (GM == 0) { tm = lid / ntiles; tn = lid - tm * ntiles; return; }
   const int per_group = GM * ntiles;
   const int grp = lid / per_group, rem = lid - grp * per_group;
   const int m_first = grp * GM;
@@ -152,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(ovg_linear_params p, int
       f32x4 v = acc[nt][mt];
       if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
       if constexpr (EPI == OVG_EPI_GELU) {
-        v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+        v[0] = gelu_erf<T>(v[0]); v[1] = gelu_erf<T>(v[1]); v[2] = gelu_erf<T>(v[2]); v[3] = gelu_erf<T>(v[3]);
       }
       if constexpr (EPI == OVG_EPI_RES) {
         const f32x4 r = *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldres + n);
@@ -179,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void qkv_kernel(ovg_qkv_params p, int nt_be
   constexpr int N = 3 * OVG_C, K = OVG_C;
   const int M = (int)p.M;
   int tm, tn;
-  tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + BM - 1) / BM, nt_count, tm, tn);
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + BM - 1) / BM, nt_count, tm, tn);   // nt_count carries GM in its high half
   const int m0 = tm * BM, n0 = (nt_begin + tn) * BN;
   f32x4 acc[4][4];
   gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
@@ -276,25 +293,28 @@ __global__ __launch_bounds__(256, 2) void qkv_kernel(ovg_qkv_params p, int nt_be
   }
 }
 
+int g_tile_group = 8;   // ovg_debug_set(0, v): tile-order group size (benchmarking knob)
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <typename T>
 int launch_linear(const ovg_linear_params& p, hipStream_t st) {
   const int mt = (int)((p.M + BM - 1) / BM), nt = (int)(p.N / BN);
   const dim3 grid(mt * nt), block(256);
+  const int ntg = nt | (g_tile_group << 16);
   switch (p.epilogue) {
     case OVG_EPI_STORE:
-      if (p.out_f32) OVG_LAUNCH((linear_kernel<T, OVG_EPI_STORE, true>), grid, block, 0, st, p, nt);
-      else OVG_LAUNCH((linear_kernel<T, OVG_EPI_STORE, false>), grid, block, 0, st, p, nt);
+      if (p.out_f32) OVG_LAUNCH((linear_kernel<T, OVG_EPI_STORE, true>), grid, block, 0, st, p, ntg);
+      else OVG_LAUNCH((linear_kernel<T, OVG_EPI_STORE, false>), grid, block, 0, st, p, ntg);
       break;
     case OVG_EPI_GELU:
-      OVG_LAUNCH((linear_kernel<T, OVG_EPI_GELU, false>), grid, block, 0, st, p, nt);
+      OVG_LAUNCH((linear_kernel<T, OVG_EPI_GELU, false>), grid, block, 0, st, p, ntg);
       break;
     case OVG_EPI_RES:
-      OVG_LAUNCH((linear_kernel<T, OVG_EPI_RES, true>), grid, block, 0, st, p, nt);
+      OVG_LAUNCH((linear_kernel<T, OVG_EPI_RES, true>), grid, block, 0, st, p, ntg);
       break;
     case OVG_EPI_PATCH:
-      OVG_LAUNCH((linear_kernel<T, OVG_EPI_PATCH, true>), grid, block, 0, st, p, nt);
+      OVG_LAUNCH((linear_kernel<T, OVG_EPI_PATCH, true>), grid, block, 0, st, p, ntg);
       break;
     default: return OVG_E_ARG;
   }
@@ -348,11 +368,16 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
   const dim3 grid((unsigned)(((p->M + BM - 1) / BM) * nt_count)), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (p->dtype) {
-    case OVG_BF16: OVG_LAUNCH((qkv_kernel<bf16_t>), grid, block, 0, st, *p, nt_begin, nt_count); break;
-    case OVG_F16: OVG_LAUNCH((qkv_kernel<f16_t>), grid, block, 0, st, *p, nt_begin, nt_count); break;
-    case OVG_F32: OVG_LAUNCH((qkv_kernel<float>), grid, block, 0, st, *p, nt_begin, nt_count); break;
+    case OVG_BF16: OVG_LAUNCH((qkv_kernel<bf16_t>), grid, block, 0, st, *p, nt_begin, nt_count | (g_tile_group << 16)); break;
+    case OVG_F16: OVG_LAUNCH((qkv_kernel<f16_t>), grid, block, 0, st, *p, nt_begin, nt_count | (g_tile_group << 16)); break;
+    case OVG_F32: OVG_LAUNCH((qkv_kernel<float>), grid, block, 0, st, *p, nt_begin, nt_count | (g_tile_group << 16)); break;
     default: return OVG_E_DTYPE;
   }
   OVG_CHECK_LAUNCH();
   return OVG_OK;
+}
+
+extern "C" int ovg_debug_set(int key, int value) {
+  if (key == 0 && value >= 0 && value < 256) { g_tile_group = value; return OVG_OK; }
+  return OVG_E_ARG;
 }

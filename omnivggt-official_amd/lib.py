@@ -113,6 +113,7 @@ SYMBOLS = {
     "ovg_assemble_tokens": (i32, [C.POINTER(AssembleParams), vp]),
     "ovg_copy_rows": (i32, [C.POINTER(CopyRowsParams), vp]),
     "ovg_probe_mfma": (i32, [vp, vp, vp, i32, vp]),
+    "ovg_debug_set": (i32, [i32, i32]),
 }
 
 

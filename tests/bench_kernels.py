@@ -93,11 +93,19 @@ def gemm(args):
                 y = torch.empty(M, N, device=DEV, dtype=dt)
                 fn = lambda: ops.linear(x, w, b, dt, epilogue=epi, out=y)
             fn()
-            ts = [timed(fn, 20) for _ in range(args.rounds)]
-            ms = statistics.median(ts)
-            tf = 2.0 * M * N * K / ms / 1e9
-            print("gemm %-5s S=%d M=%d N=%d K=%d: median %.3f ms  %.1f TFLOP/s (%.1f%% of 2.5PF)" % (nm, S, M, N, K, ms, tf, tf / 25.0), flush=True)
-            out["gemm_%s_S%d" % (nm, S)] = {"ms": ms, "tflops": tf}
+            groups = args.tile_groups
+            ts = {gm: [] for gm in groups}
+            for _ in range(args.rounds):
+                for gm in groups:                      # interleaved A/B of the tile-order knob
+                    L.load().ovg_debug_set(0, gm)
+                    ts[gm].append(timed(fn, 20))
+            L.load().ovg_debug_set(0, 8)
+            for gm in groups:
+                ms = statistics.median(ts[gm])
+                tf = 2.0 * M * N * K / ms / 1e9
+                print("gemm %-5s S=%d M=%d N=%d K=%d group=%d: median %.3f ms  %.1f TFLOP/s (%.1f%% of 2.5PF)"
+                      % (nm, S, M, N, K, gm, ms, tf, tf / 25.0), flush=True)
+                out["gemm_%s_S%d_g%d" % (nm, S, gm)] = {"ms": ms, "tflops": tf}
     return out
 
 
@@ -108,6 +116,7 @@ def main():
     ap.add_argument("--variants", type=int, nargs="+", default=[1, 2, 3, 4, 5])
     ap.add_argument("--modes", nargs="+", default=["global", "frame"])
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--tile-groups", type=int, nargs="+", default=[8])
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--target-ms", type=float, default=20.0)
     ap.add_argument("--out", default="")
