@@ -136,17 +136,93 @@ OVG_DEV void gemm_mainloop(const T* __restrict__ X, int64_t ldx, const T* __rest
 }
 
 // ---------------------------------------------------------------------------
+// Main loop, LDS-DMA flavour: global -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no
+// ds_write), double-buffered, ONE barrier per k-step.  A wave-instruction deposits lane l's 16 bytes
+// at (wave-uniform LDS base) + 16*l, i.e. 8 consecutive 128-byte tile rows; the XOR swizzle is
+// therefore applied to the per-lane SOURCE address (global chunk = lds chunk ^ swizzle(row)) and
+// again on the fragment reads -- the destination stays linear.
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <typename T>
+OVG_DEV void gemm_mainloop_glds(const T* __restrict__ X, int64_t ldx, const T* __restrict__ W, int64_t ldw,
+                                int M, int N, int K, int m0, int n0, unsigned char* lds, f32x4 (&acc)[4][4]) {
+  constexpr int BKB = 128, TILE = 128 * BKB, BUF = 2 * TILE;     // bytes: one operand tile, one buffer (W|X)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wm = wave & 1;
+  const int g = lane >> 4, lr = lane & 15;
+
+  // wave w stages rows [32w, 32w+32) of each operand tile: 4 wave-instructions of 8 rows each
+  const unsigned char* xg[4];
+  const unsigned char* wg[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + (lane >> 3);
+    const int ch = (lane & 7) ^ ((row >> 1) & 7);                 // source chunk for linear LDS slot (lane&7)
+    int xr = m0 + row; xr = xr < M ? xr : M - 1;
+    int wr = n0 + row; wr = wr < N ? wr : N - 1;
+    xg[i] = reinterpret_cast<const unsigned char*>(X + (int64_t)xr * ldx) + ch * 16;
+    wg[i] = reinterpret_cast<const unsigned char*>(W + (int64_t)wr * ldw) + ch * 16;
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (K * (int)sizeof(T)) / BKB;
+  auto stage = [&](int kt, int buf) {
+    unsigned char* wb = lds + buf * BUF + wave * 32 * BKB;        // wave-uniform destinations
+    unsigned char* xb = wb + TILE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(wg[i] + (int64_t)kt * BKB), (lptr_t)(wb + i * 8 * BKB), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(xg[i] + (int64_t)kt * BKB), (lptr_t)(xb + i * 8 * BKB), 16, 0, 0);
+    }
+  };
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int sx = lr >> 1;
+  const int wrow = (wn * 64 + lr) * 128, xrow = TILE + (wm * 64 + lr) * 128;
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+    const unsigned char* base = lds + buf * BUF;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int coff = ((kk * 4 + g) ^ sx) << 4;
+      u32x4 a[4], b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a[t] = *reinterpret_cast<const u32x4*>(base + wrow + t * 16 * 128 + coff);
+        b[t] = *reinterpret_cast<const u32x4*>(base + xrow + t * 16 * 128 + coff);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) TT<T>::mma(acc[nt][mt], a[nt], b[mt]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Linear kernel (STORE / GELU / RES / PATCH epilogues)
 // ---------------------------------------------------------------------------
-template <typename T, int EPI, bool OUT_F32>
+template <typename T, int EPI, bool OUT_F32, bool GLDS>
 __global__ __launch_bounds__(256, 2) void linear_kernel(ovg_linear_params p, int ntiles_n) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(GLDS ? 4 : 2) * 128 * 128];
   const int M = (int)p.M, N = (int)p.N, K = (int)p.K;
   int tm, tn;
   tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + BM - 1) / BM, ntiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   f32x4 acc[4][4];
-  gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds, acc);
+  if constexpr (GLDS) gemm_mainloop_glds<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds, acc);
+  else gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds, acc);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wn = wave >> 1, wm = wave & 1, g = lane >> 4, lr = lane & 15;
@@ -190,16 +266,17 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(ovg_linear_params p, int
 // ---------------------------------------------------------------------------
 // QKV kernel: bias + per-head LayerNorm(64) + 2-D RoPE + q scale, head-major stores
 // ---------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool GLDS>
 __global__ __launch_bounds__(256, 2) void qkv_kernel(ovg_qkv_params p, int nt_begin, int nt_count) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(GLDS ? 4 : 2) * 128 * 128];
   constexpr int N = 3 * OVG_C, K = OVG_C;
   const int M = (int)p.M;
   int tm, tn;
   tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + BM - 1) / BM, nt_count, tm, tn);   // nt_count carries GM in its high half
   const int m0 = tm * BM, n0 = (nt_begin + tn) * BN;
   f32x4 acc[4][4];
-  gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
+  if constexpr (GLDS) gemm_mainloop_glds<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
+  else gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wn = wave >> 1, wm = wave & 1, g = lane >> 4, lr = lane & 15;
@@ -297,29 +374,35 @@ int g_tile_group = 8;   // ovg_debug_set(0, v): tile-order group size (benchmark
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <typename T>
-int launch_linear(const ovg_linear_params& p, hipStream_t st) {
+int g_mainloop = 0;     // ovg_debug_set(1, v): 0 = register-staged main loop, 1 = LDS-DMA (global_load_lds)
+
+template <typename T, bool GLDS>
+int launch_linear_ml(const ovg_linear_params& p, hipStream_t st) {
   const int mt = (int)((p.M + BM - 1) / BM), nt = (int)(p.N / BN);
   const dim3 grid(mt * nt), block(256);
   const int ntg = nt | (g_tile_group << 16);
   switch (p.epilogue) {
     case OVG_EPI_STORE:
-      if (p.out_f32) OVG_LAUNCH((linear_kernel<T, OVG_EPI_STORE, true>), grid, block, 0, st, p, ntg);
-      else OVG_LAUNCH((linear_kernel<T, OVG_EPI_STORE, false>), grid, block, 0, st, p, ntg);
+      if (p.out_f32) OVG_LAUNCH((linear_kernel<T, OVG_EPI_STORE, true, GLDS>), grid, block, 0, st, p, ntg);
+      else OVG_LAUNCH((linear_kernel<T, OVG_EPI_STORE, false, GLDS>), grid, block, 0, st, p, ntg);
       break;
     case OVG_EPI_GELU:
-      OVG_LAUNCH((linear_kernel<T, OVG_EPI_GELU, false>), grid, block, 0, st, p, ntg);
+      OVG_LAUNCH((linear_kernel<T, OVG_EPI_GELU, false, GLDS>), grid, block, 0, st, p, ntg);
       break;
     case OVG_EPI_RES:
-      OVG_LAUNCH((linear_kernel<T, OVG_EPI_RES, true>), grid, block, 0, st, p, ntg);
+      OVG_LAUNCH((linear_kernel<T, OVG_EPI_RES, true, GLDS>), grid, block, 0, st, p, ntg);
       break;
     case OVG_EPI_PATCH:
-      OVG_LAUNCH((linear_kernel<T, OVG_EPI_PATCH, true>), grid, block, 0, st, p, ntg);
+      OVG_LAUNCH((linear_kernel<T, OVG_EPI_PATCH, true, GLDS>), grid, block, 0, st, p, ntg);
       break;
     default: return OVG_E_ARG;
   }
   OVG_CHECK_LAUNCH();
   return OVG_OK;
+}
+template <typename T>
+int launch_linear(const ovg_linear_params& p, hipStream_t st) {
+  return g_mainloop ? launch_linear_ml<T, true>(p, st) : launch_linear_ml<T, false>(p, st);
 }
 
 }  // namespace
@@ -367,10 +450,11 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
   const int nt_count = p->part == 0 ? all_tiles : (p->part == 1 ? all_tiles - q_tiles : q_tiles);
   const dim3 grid((unsigned)(((p->M + BM - 1) / BM) * nt_count)), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const int ntg = nt_count | (g_tile_group << 16);
   switch (p->dtype) {
-    case OVG_BF16: OVG_LAUNCH((qkv_kernel<bf16_t>), grid, block, 0, st, *p, nt_begin, nt_count | (g_tile_group << 16)); break;
-    case OVG_F16: OVG_LAUNCH((qkv_kernel<f16_t>), grid, block, 0, st, *p, nt_begin, nt_count | (g_tile_group << 16)); break;
-    case OVG_F32: OVG_LAUNCH((qkv_kernel<float>), grid, block, 0, st, *p, nt_begin, nt_count | (g_tile_group << 16)); break;
+    case OVG_BF16: if (g_mainloop) OVG_LAUNCH((qkv_kernel<bf16_t, true>), grid, block, 0, st, *p, nt_begin, ntg); else OVG_LAUNCH((qkv_kernel<bf16_t, false>), grid, block, 0, st, *p, nt_begin, ntg); break;
+    case OVG_F16: if (g_mainloop) OVG_LAUNCH((qkv_kernel<f16_t, true>), grid, block, 0, st, *p, nt_begin, ntg); else OVG_LAUNCH((qkv_kernel<f16_t, false>), grid, block, 0, st, *p, nt_begin, ntg); break;
+    case OVG_F32: if (g_mainloop) OVG_LAUNCH((qkv_kernel<float, true>), grid, block, 0, st, *p, nt_begin, ntg); else OVG_LAUNCH((qkv_kernel<float, false>), grid, block, 0, st, *p, nt_begin, ntg); break;
     default: return OVG_E_DTYPE;
   }
   OVG_CHECK_LAUNCH();
@@ -379,5 +463,6 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
 
 extern "C" int ovg_debug_set(int key, int value) {
   if (key == 0 && value >= 0 && value < 256) { g_tile_group = value; return OVG_OK; }
+  if (key == 1 && (value == 0 || value == 1)) { g_mainloop = value; return OVG_OK; }
   return OVG_E_ARG;
 }

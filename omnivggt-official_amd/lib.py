@@ -145,6 +145,11 @@ def load(build_if_missing=True):
         fn.argtypes = args
     if lib.ovg_abi_version() != ABI_VERSION:
         raise OvgError("ABI version mismatch: library %d, binding %d" % (lib.ovg_abi_version(), ABI_VERSION))
+    # benchmarking knobs (see ovg_debug_set in the header); never needed for correctness
+    if os.environ.get("OVG_GEMM_TILE_GROUP"):
+        lib.ovg_debug_set(0, int(os.environ["OVG_GEMM_TILE_GROUP"]))
+    if os.environ.get("OVG_GEMM_MAINLOOP"):
+        lib.ovg_debug_set(1, int(os.environ["OVG_GEMM_MAINLOOP"]))
     _lib = lib
     return lib
 

@@ -93,19 +93,21 @@ def gemm(args):
                 y = torch.empty(M, N, device=DEV, dtype=dt)
                 fn = lambda: ops.linear(x, w, b, dt, epilogue=epi, out=y)
             fn()
-            groups = args.tile_groups
-            ts = {gm: [] for gm in groups}
+            combos = [(gm, ml) for gm in args.tile_groups for ml in args.mainloops]
+            ts = {c: [] for c in combos}
             for _ in range(args.rounds):
-                for gm in groups:                      # interleaved A/B of the tile-order knob
+                for gm, ml in combos:                  # interleaved A/B of the tuning knobs
                     L.load().ovg_debug_set(0, gm)
-                    ts[gm].append(timed(fn, 20))
+                    L.load().ovg_debug_set(1, ml)
+                    ts[(gm, ml)].append(timed(fn, 20))
             L.load().ovg_debug_set(0, 8)
-            for gm in groups:
-                ms = statistics.median(ts[gm])
+            L.load().ovg_debug_set(1, 0)
+            for gm, ml in combos:
+                ms = statistics.median(ts[(gm, ml)])
                 tf = 2.0 * M * N * K / ms / 1e9
-                print("gemm %-5s S=%d M=%d N=%d K=%d group=%d: median %.3f ms  %.1f TFLOP/s (%.1f%% of 2.5PF)"
-                      % (nm, S, M, N, K, gm, ms, tf, tf / 25.0), flush=True)
-                out["gemm_%s_S%d_g%d" % (nm, S, gm)] = {"ms": ms, "tflops": tf}
+                print("gemm %-5s S=%d M=%d N=%d K=%d group=%d mainloop=%d: median %.3f ms  %.1f TFLOP/s (%.1f%% of 2.5PF)"
+                      % (nm, S, M, N, K, gm, ml, ms, tf, tf / 25.0), flush=True)
+                out["gemm_%s_S%d_g%d_ml%d" % (nm, S, gm, ml)] = {"ms": ms, "tflops": tf}
     return out
 
 
@@ -117,6 +119,7 @@ def main():
     ap.add_argument("--modes", nargs="+", default=["global", "frame"])
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--tile-groups", type=int, nargs="+", default=[8])
+    ap.add_argument("--mainloops", type=int, nargs="+", default=[0], help="0 = register-staged, 1 = LDS-DMA")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--target-ms", type=float, default=20.0)
     ap.add_argument("--out", default="")
