@@ -41,12 +41,25 @@ def agg_flops(S):
     return S * (72 * 34.58e9 + 48 * 7.73e9 + 1.65e9) + f_ga, f_ga
 
 
-def synthetic_inputs(S, device, seed=1234):
+def synthetic_inputs(S, device, seed=1234, aux=False):
+    """SURVEY.md section 8d inputs: images U[0,1); with aux also random-rotation cameras, depth 0.5+5U,
+    mask Bernoulli(0.8).  Images-only runs carry the loader's zero placeholders (visual_util.py:793-824)."""
     g = torch.Generator().manual_seed(seed)
     images = torch.rand(1, S, 3, 518, 518, generator=g)
     z = lambda *s: torch.zeros(*s)
-    return dict(images=images.to(device), extrinsics=z(1, S, 3, 4).to(device), intrinsics=z(1, S, 3, 3).to(device),
-                depth=z(1, S, 518, 518, 1).to(device), mask=z(1, S, 518, 518).to(device))
+    if not aux:
+        return dict(images=images.to(device), extrinsics=z(1, S, 3, 4).to(device), intrinsics=z(1, S, 3, 3).to(device),
+                    depth=z(1, S, 518, 518, 1).to(device), mask=z(1, S, 518, 518).to(device))
+    from omnivggt_official_amd.camera_math import quaternion_to_rotation
+    q = torch.randn(S, 4, generator=g)
+    R = quaternion_to_rotation(q / q.norm(dim=-1, keepdim=True))
+    ext = torch.cat([R, torch.randn(S, 3, 1, generator=g)], dim=-1).unsqueeze(0)
+    f = 400 + 300 * torch.rand(S, generator=g)
+    K = torch.zeros(1, S, 3, 3)
+    K[0, :, 0, 0], K[0, :, 1, 1], K[0, :, 0, 2], K[0, :, 1, 2], K[0, :, 2, 2] = f, f, 259.0, 259.0, 1.0
+    depth = 0.5 + 5 * torch.rand(1, S, 518, 518, 1, generator=g)
+    mask = (torch.rand(1, S, 518, 518, generator=g) > 0.2).float()
+    return dict(images=images.to(device), extrinsics=ext.to(device), intrinsics=K.to(device), depth=depth.to(device), mask=mask.to(device))
 
 
 def main():
@@ -59,6 +72,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e", action="store_true", help="also time OmniVGGT.forward incl. the PyTorch heads (MIOpen JIT makes the first call slow)")
     ap.add_argument("--attn-variant", type=int, default=0)
+    ap.add_argument("--aux", action="store_true", help="depth + camera tokens on every view (BASELINE configs[2] with --views 16)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,7 +105,8 @@ def main():
     if world > 1:
         from omnivggt_official_amd.sharding import ViewSharding
         agg.shard = ViewSharding(gather_output=False)
-    inp = synthetic_inputs(S, dev)
+    inp = synthetic_inputs(S, dev, aux=args.aux)
+    idx = list(range(S)) if args.aux else []
 
     # live HIP-event timing of the global-attention launches inside the timed steps
     n_local = S // world + (1 if rank < S % world else 0)
@@ -99,7 +114,7 @@ def main():
     ev = agg.enable_attention_events(args.steps * agg.depth)
 
     def step():
-        return agg(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], [], [])
+        return agg(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], idx, idx)
 
     def barrier():
         if dist is not None:
@@ -138,13 +153,15 @@ def main():
         "metric": "frames/sec (518^2, S views) aggregator hot path", "value": round(fps, 3), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "OmniVGGT aggregator forward, %d views 518x518 images-only (BASELINE configs[%s]), %d views/GPU, "
-                               "view-sharded global attention" % (S, "1" if world == 1 and S == 8 else ("3" if S == 64 else "-"), n_local),
+        "config": {"workload": "OmniVGGT aggregator forward, %d views 518x518 %s (BASELINE configs[%s]), %d views/GPU, "
+                               "view-sharded global attention" % (S, "+ depth + camera tokens" if args.aux else "images-only",
+                                                                   ("2" if args.aux and S == 16 else "-") if args.aux else
+                                                                   ("1" if world == 1 and S == 8 else ("3" if S == 64 else "-")), n_local),
                    "views": S, "views_per_gpu": n_local, "tokens": S * P_TOK, "weights": "seeded synthetic (no checkpoint offline)",
                    "parallelism": "view-shard x%d" % world},
         "algorithmic_tflop_per_step": round(f_total / 1e12, 2),
         "tflops_per_gpu": round(f_total / 1e12 / (dt / args.steps) / world, 1),
-        "roofline": {"bound": "mfma", "kernel": "attn_kernel (global attention, D=64)", "achieved": round(achieved, 1), "peak": peak,
+        "roofline": {"bound": "mfma", "kernel": "attn3_kernel<bf16,QB=4,WAVES=4> (global cross-view attention, D=64)" if args.dtype != "f32" else "attn_kernel<float,1>", "achieved": round(achieved, 1), "peak": peak,
                      "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                      "flop_per_launch": launch_flops, "avg_launch_ms": round(attn_avg_ms, 4), "launches_timed": len(attn_ms)},
     }
@@ -158,7 +175,7 @@ def main():
                 pass
         if args.e2e:
             try:
-                full = lambda: model(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], [], [])
+                full = lambda: model(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], idx, idx)
                 full()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
