@@ -43,7 +43,7 @@ template <typename T> OVG_DEV float gelu_erf(float x) {
 // the whole weight matrix per m-tile (measured with plain n-fastest order: 61 % L2 hit rate, 590 MB of
 // fabric reads for a 30 MB problem on fc1).
 OVG_DEV void tile_coords(int lid, int mtiles, int ntiles_gm, int& tm, int& tn) {
-  const int ntiles = ntiles_gm & 0xffff, GM = ntiles_gm >> 16;   // GM == 0: plain n-fastest order
+  const int ntiles = ntiles_gm & 0xffff, GM = (ntiles_gm >> 16) & 0xff;   // GM == 0: plain n-fastest order
   if (GM == 0) { tm = lid / ntiles; tn = lid - tm * ntiles; return; }
   const int per_group = GM * ntiles;
   const int grp = lid / per_group, rem = lid - grp * per_group;
@@ -145,7 +145,7 @@ OVG_DEV void gemm_mainloop(const T* __restrict__ X, int64_t ldx, const T* __rest
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <typename T>
+template <typename T, int ABL>   // ABL (diagnostic builds): 1 = no loads inside the loop, 2 = no MFMA
 OVG_DEV void gemm_mainloop_glds(const T* __restrict__ X, int64_t ldx, const T* __restrict__ W, int64_t ldw,
                                 int M, int N, int K, int m0, int n0, unsigned char* lds, f32x4 (&acc)[4][4]) {
   constexpr int BKB = 128, TILE = 128 * BKB, BUF = 2 * TILE;     // bytes: one operand tile, one buffer (W|X)
@@ -188,7 +188,7 @@ OVG_DEV void gemm_mainloop_glds(const T* __restrict__ X, int64_t ldx, const T* _
   const int wrow = (wn * 64 + lr) * 128, xrow = TILE + (wm * 64 + lr) * 128;
   int buf = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+    if (kt + 1 < nk && ABL != 1) stage(kt + 1, buf ^ 1);
     const unsigned char* base = lds + buf * BUF;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -199,10 +199,15 @@ OVG_DEV void gemm_mainloop_glds(const T* __restrict__ X, int64_t ldx, const T* _
         a[t] = *reinterpret_cast<const u32x4*>(base + wrow + t * 16 * 128 + coff);
         b[t] = *reinterpret_cast<const u32x4*>(base + xrow + t * 16 * 128 + coff);
       }
+      if constexpr (ABL != 2) {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) TT<T>::mma(acc[nt][mt], a[nt], b[mt]);
+          for (int mt = 0; mt < 4; ++mt) TT<T>::mma(acc[nt][mt], a[nt], b[mt]);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) asm volatile("" :: "v"(a[t]), "v"(b[t]));
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -213,7 +218,7 @@ OVG_DEV void gemm_mainloop_glds(const T* __restrict__ X, int64_t ldx, const T* _
 // ---------------------------------------------------------------------------
 // Linear kernel (STORE / GELU / RES / PATCH epilogues)
 // ---------------------------------------------------------------------------
-template <typename T, int EPI, bool OUT_F32, bool GLDS>
+template <typename T, int EPI, bool OUT_F32, int GLDS>   // GLDS: 0 register-staged, 1 LDS-DMA, 2/3 LDS-DMA ablations
 __global__ __launch_bounds__(256, 2) void linear_kernel(ovg_linear_params p, int ntiles_n) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[(GLDS ? 4 : 2) * 128 * 128];
   const int M = (int)p.M, N = (int)p.N, K = (int)p.K;
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(ovg_linear_params p, int
   tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + BM - 1) / BM, ntiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   f32x4 acc[4][4];
-  if constexpr (GLDS) gemm_mainloop_glds<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds, acc);
+  if constexpr (GLDS != 0) gemm_mainloop_glds<T, GLDS - 1>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds, acc);
   else gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds, acc);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void qkv_kernel(ovg_qkv_params p, int nt_be
   tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + BM - 1) / BM, nt_count, tm, tn);   // nt_count carries GM in its high half
   const int m0 = tm * BM, n0 = (nt_begin + tn) * BN;
   f32x4 acc[4][4];
-  if constexpr (GLDS) gemm_mainloop_glds<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
+  if constexpr (GLDS) gemm_mainloop_glds<T, 0>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
   else gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -376,7 +381,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 int g_mainloop = 0;     // ovg_debug_set(1, v): 0 = register-staged main loop, 1 = LDS-DMA (global_load_lds)
 
-template <typename T, bool GLDS>
+template <typename T, int GLDS>
 int launch_linear_ml(const ovg_linear_params& p, hipStream_t st) {
   const int mt = (int)((p.M + BM - 1) / BM), nt = (int)(p.N / BN);
   const dim3 grid(mt * nt), block(256);
@@ -402,7 +407,17 @@ int launch_linear_ml(const ovg_linear_params& p, hipStream_t st) {
 }
 template <typename T>
 int launch_linear(const ovg_linear_params& p, hipStream_t st) {
-  return g_mainloop ? launch_linear_ml<T, true>(p, st) : launch_linear_ml<T, false>(p, st);
+  if constexpr (sizeof(T) == 2) {           // ablation builds exist for the bf16/f16 RES epilogue only
+    if (g_mainloop >= 2 && p.epilogue == OVG_EPI_RES) {
+      const int mt = (int)((p.M + BM - 1) / BM), nt = (int)(p.N / BN);
+      const int ntg = nt | (g_tile_group << 16);
+      if (g_mainloop == 2) OVG_LAUNCH((linear_kernel<T, OVG_EPI_RES, true, 2>), dim3(mt * nt), dim3(256), 0, st, p, ntg);
+      else OVG_LAUNCH((linear_kernel<T, OVG_EPI_RES, true, 3>), dim3(mt * nt), dim3(256), 0, st, p, ntg);
+      OVG_CHECK_LAUNCH();
+      return OVG_OK;
+    }
+  }
+  return g_mainloop == 1 ? launch_linear_ml<T, 1>(p, st) : launch_linear_ml<T, 0>(p, st);
 }
 
 }  // namespace
@@ -452,9 +467,9 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int ntg = nt_count | (g_tile_group << 16);
   switch (p->dtype) {
-    case OVG_BF16: if (g_mainloop) OVG_LAUNCH((qkv_kernel<bf16_t, true>), grid, block, 0, st, *p, nt_begin, ntg); else OVG_LAUNCH((qkv_kernel<bf16_t, false>), grid, block, 0, st, *p, nt_begin, ntg); break;
-    case OVG_F16: if (g_mainloop) OVG_LAUNCH((qkv_kernel<f16_t, true>), grid, block, 0, st, *p, nt_begin, ntg); else OVG_LAUNCH((qkv_kernel<f16_t, false>), grid, block, 0, st, *p, nt_begin, ntg); break;
-    case OVG_F32: if (g_mainloop) OVG_LAUNCH((qkv_kernel<float, true>), grid, block, 0, st, *p, nt_begin, ntg); else OVG_LAUNCH((qkv_kernel<float, false>), grid, block, 0, st, *p, nt_begin, ntg); break;
+    case OVG_BF16: if (g_mainloop == 1) OVG_LAUNCH((qkv_kernel<bf16_t, true>), grid, block, 0, st, *p, nt_begin, ntg); else OVG_LAUNCH((qkv_kernel<bf16_t, false>), grid, block, 0, st, *p, nt_begin, ntg); break;
+    case OVG_F16: if (g_mainloop == 1) OVG_LAUNCH((qkv_kernel<f16_t, true>), grid, block, 0, st, *p, nt_begin, ntg); else OVG_LAUNCH((qkv_kernel<f16_t, false>), grid, block, 0, st, *p, nt_begin, ntg); break;
+    case OVG_F32: if (g_mainloop == 1) OVG_LAUNCH((qkv_kernel<float, true>), grid, block, 0, st, *p, nt_begin, ntg); else OVG_LAUNCH((qkv_kernel<float, false>), grid, block, 0, st, *p, nt_begin, ntg); break;
     default: return OVG_E_DTYPE;
   }
   OVG_CHECK_LAUNCH();
@@ -463,6 +478,6 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
 
 extern "C" int ovg_debug_set(int key, int value) {
   if (key == 0 && value >= 0 && value < 256) { g_tile_group = value; return OVG_OK; }
-  if (key == 1 && (value == 0 || value == 1)) { g_mainloop = value; return OVG_OK; }
+  if (key == 1 && value >= 0 && value <= 3) { g_mainloop = value; return OVG_OK; }
   return OVG_E_ARG;
 }

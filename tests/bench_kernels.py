@@ -94,6 +94,8 @@ def gemm(args):
                 fn = lambda: ops.linear(x, w, b, dt, epilogue=epi, out=y)
             fn()
             combos = [(gm, ml) for gm in args.tile_groups for ml in args.mainloops]
+            if args.ablate:
+                combos = [(8, 0), (8, 1), (8, 2), (8, 3)]        # 2/3 = LDS-DMA loop without loads / without MFMAs (RES epilogue only)
             ts = {c: [] for c in combos}
             for _ in range(args.rounds):
                 for gm, ml in combos:                  # interleaved A/B of the tuning knobs
@@ -120,6 +122,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--tile-groups", type=int, nargs="+", default=[8])
     ap.add_argument("--mainloops", type=int, nargs="+", default=[0], help="0 = register-staged, 1 = LDS-DMA")
+    ap.add_argument("--ablate", action="store_true", help="GEMM: also time the LDS-DMA loop without loads / without MFMAs")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--target-ms", type=float, default=20.0)
     ap.add_argument("--out", default="")
