@@ -7,11 +7,13 @@
 
 A "step" is ONE forward of the aggregator (DINOv2 embed + modality fusion + 24 x [frame block,
 camera injection, global block]) over one synthetic multi-view batch already resident in HBM.
-N=1: BASELINE.json configs[1] (8 views, 518^2, images-only, bf16).  N>1: 8 views per GPU
-(view-sharded, K/V^T all-gather over RCCL) -- N=8 is configs[3] (64 views); "scaling":"weak"
-means views per GPU are fixed (global-attention work per view still grows with S, so the
-JSON also carries algorithmic TFLOP/s per GPU).  --views overrides the total view count
-(e.g. --views 64 at every N for the strong-scaling curve of the north star).
+Default workload at every N: 64 views, 518^2, images-only, bf16 -- BASELINE.json configs[3] and the
+north star's scaling statement ("frames/sec at 1/2/4/8 GPUs ... on 64-view 518^2 synthetic input";
+SURVEY.md section 8d: "Config 4 ... also run G=1,2,4 for the scaling curve"), so `python bench.py --gpus N`
+for N=1,2,4,8 IS that strong-scaling curve ("scaling": "strong": total work fixed, views sharded
+over the ranks, K/V^T all-gather over RCCL).  At N=1 the same JSON line also carries `secondary`:
+the 8-view configs[1] measurement (frames/s + roofline of the same kernel on that shape).
+--views S overrides the view count; --aux adds depth + camera tokens on every view (configs[2]).
 
 Prints ONE JSON line on rank 0 (metric frames/s, roofline of the global-attention kernel
 measured live with HIP events inside the timed steps, cpu_baseline = oracle on host cores).
@@ -67,7 +69,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--views", type=int, default=0, help="total views S (default 8 per GPU)")
+    ap.add_argument("--views", type=int, default=0, help="total views S (default 64 at every N)")
     ap.add_argument("--dtype", default="bf16", choices=list(DT))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e", action="store_true", help="also time OmniVGGT.forward incl. the PyTorch heads (MIOpen JIT makes the first call slow)")
@@ -91,7 +93,6 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    S = args.views or 8 * world
     dtype = DT[args.dtype]
     with torch.device("meta"):
         model = OmniVGGT(compute_dtype=dtype)
@@ -105,66 +106,70 @@ def main():
     if world > 1:
         from omnivggt_official_amd.sharding import ViewSharding
         agg.shard = ViewSharding(gather_output=False)
-    inp = synthetic_inputs(S, dev, aux=args.aux)
-    idx = list(range(S)) if args.aux else []
+    def measure(S, steps, warmup):
+        """Time `steps` aggregator forwards on S views; returns the result dict (rank-reduced)."""
+        inp = synthetic_inputs(S, dev, aux=args.aux)
+        idx = list(range(S)) if args.aux else []
+        n_local = S // world + (1 if rank < S % world else 0)
+        nq_local, nk_total = n_local * P_TOK, S * P_TOK
+        agg.enable_attention_events(steps * agg.depth)   # live HIP-event timing of the global-attention launches
 
-    # live HIP-event timing of the global-attention launches inside the timed steps
-    n_local = S // world + (1 if rank < S % world else 0)
-    nq_local, nk_total = n_local * P_TOK, S * P_TOK
-    ev = agg.enable_attention_events(args.steps * agg.depth)
+        def step():
+            return agg(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], idx, idx)
 
-    def step():
-        return agg(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], idx, idx)
+        def barrier():
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    agg.reset_attention_events()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    attn_ms = agg.attention_event_times()
-    agg.disable_attention_events()
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        a = torch.tensor([sum(attn_ms) / max(len(attn_ms), 1)], device=dev, dtype=torch.float64)
-        dist.all_reduce(a, op=dist.ReduceOp.MAX)
-        attn_avg_ms = float(a.item())
-    else:
+        for _ in range(warmup):
+            step()
+        agg.reset_attention_events()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        attn_ms = agg.attention_event_times()
+        agg.disable_attention_events()
         attn_avg_ms = sum(attn_ms) / max(len(attn_ms), 1)
+        if dist is not None:
+            t = torch.tensor([dt, attn_avg_ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt, attn_avg_ms = float(t[0].item()), float(t[1].item())
+        f_total, f_ga = agg_flops(S)
+        launch_flops = 4.0 * nq_local * nk_total * 1024           # one global-attention launch on this rank
+        achieved = launch_flops / (attn_avg_ms * 1e-3) / 1e12 if attn_avg_ms > 0 else 0.0
+        peak = PEAK_TFLOPS[args.dtype]
+        cfg = "2" if (args.aux and S == 16) else ("-" if args.aux else {8: "1", 64: "3"}.get(S, "-"))
+        res = {
+            "value": round(S * steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 3),
+            "config": {"workload": "OmniVGGT aggregator forward, %d views 518x518 %s (BASELINE configs[%s]), view-sharded over %d GPU(s)"
+                                   % (S, "+ depth + camera tokens" if args.aux else "images-only", cfg, world),
+                       "views": S, "views_per_gpu": n_local, "tokens": S * P_TOK, "weights": "seeded synthetic (no checkpoint offline)",
+                       "parallelism": "view-shard x%d" % world},
+            "algorithmic_tflop_per_step": round(f_total / 1e12, 2),
+            "tflops_per_gpu": round(f_total / 1e12 / (dt / steps) / world, 1),
+            "roofline": {"bound": "mfma", "kernel": ("attn3_kernel<bf16,QB=4,WAVES=4>" if args.dtype != "f32" else "attn_kernel<float,1>")
+                         + " (global cross-view attention, D=64)", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None, "flop_per_launch": launch_flops,
+                         "avg_launch_ms": round(attn_avg_ms, 4), "launches_timed": len(attn_ms)},
+        }
+        del inp
+        torch.cuda.empty_cache()
+        return res
 
-    ms_per_step = dt / args.steps * 1e3
-    fps = S * args.steps / dt
-    f_total, f_ga = agg_flops(S)
-    launch_flops = 4.0 * nq_local * nk_total * 1024           # one global-attention launch on this rank
-    achieved = launch_flops / (attn_avg_ms * 1e-3) / 1e12 if attn_avg_ms > 0 else 0.0
-    peak = PEAK_TFLOPS[args.dtype]
-
-    result = {
-        "metric": "frames/sec (518^2, S views) aggregator hot path", "value": round(fps, 3), "unit": "frames/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "OmniVGGT aggregator forward, %d views 518x518 %s (BASELINE configs[%s]), %d views/GPU, "
-                               "view-sharded global attention" % (S, "+ depth + camera tokens" if args.aux else "images-only",
-                                                                   ("2" if args.aux and S == 16 else "-") if args.aux else
-                                                                   ("1" if world == 1 and S == 8 else ("3" if S == 64 else "-")), n_local),
-                   "views": S, "views_per_gpu": n_local, "tokens": S * P_TOK, "weights": "seeded synthetic (no checkpoint offline)",
-                   "parallelism": "view-shard x%d" % world},
-        "algorithmic_tflop_per_step": round(f_total / 1e12, 2),
-        "tflops_per_gpu": round(f_total / 1e12 / (dt / args.steps) / world, 1),
-        "roofline": {"bound": "mfma", "kernel": "attn3_kernel<bf16,QB=4,WAVES=4> (global cross-view attention, D=64)" if args.dtype != "f32" else "attn_kernel<float,1>", "achieved": round(achieved, 1), "peak": peak,
-                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-                     "flop_per_launch": launch_flops, "avg_launch_ms": round(attn_avg_ms, 4), "launches_timed": len(attn_ms)},
-    }
+    S = args.views or 64
+    primary = measure(S, args.steps, args.warmup)
+    result = {"metric": "frames/sec (518^2, S views) aggregator hot path", "value": primary["value"], "unit": "frames/s",
+              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": primary["ms_per_step"],
+              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic"}
+    result.update({k: primary[k] for k in ("config", "algorithmic_tflop_per_step", "tflops_per_gpu", "roofline")})
+    if world == 1 and S != 8 and not args.views:
+        sec = measure(8, 10, 3)                                      # BASELINE configs[1] on the same process
+        result["secondary"] = {"frames_per_s": sec["value"], "ms_per_step": sec["ms_per_step"], "config": sec["config"],
+                               "tflops_per_gpu": sec["tflops_per_gpu"], "roofline": sec["roofline"]}
 
     if rank == 0 and world == 1:
         tr = os.path.join(ROOT, "profiles", "traffic.json")
@@ -175,6 +180,8 @@ def main():
                 pass
         if args.e2e:
             try:
+                inp = synthetic_inputs(8, dev, aux=args.aux)
+                idx = list(range(8)) if args.aux else []
                 full = lambda: model(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], idx, idx)
                 full()
                 torch.cuda.synchronize()
@@ -182,7 +189,7 @@ def main():
                 for _ in range(2):
                     full()
                 torch.cuda.synchronize()
-                result["e2e_frames_per_s_with_pytorch_heads"] = round(S * 2 / (time.perf_counter() - t1), 3)
+                result["e2e_S8_frames_per_s_with_pytorch_heads"] = round(8 * 2 / (time.perf_counter() - t1), 3)
             except Exception as e:  # heads are stock PyTorch; never let them hide the hot-path number
                 result["e2e_error"] = repr(e)[:200]
         if not args.no_cpu_baseline:
