@@ -15,7 +15,7 @@ template <typename T> struct OnesFrag;
 template <> struct OnesFrag<bf16_t> { static OVG_DEV u32x4 get() { return u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}; } };
 template <> struct OnesFrag<f16_t> { static OVG_DEV u32x4 get() { return u32x4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u}; } };
 
-template <typename T, int QB, int WAVES>
+template <typename T, int QB, int WAVES, bool PRIO = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void attn3_kernel(ovg_attn_params p, int nqt, int total_tiles) {
   static_assert(sizeof(T) == 2, "16-bit types only");
   constexpr int NT = 64 * WAVES;
@@ -119,6 +119,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn3_kernel(ovg_attn_params p,
 
     // ---- S' = K Q^T - m_ref ----------------------------------------------
     f32x4 s[QB][4];
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       const u32x4 k0 = *reinterpret_cast<const u32x4*>(kl + kt * 2048 + frag_row + coff0);
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn3_kernel(ovg_attn_params p,
         s[qb][kt] = mma_c<T>(k1, qf[qb][1], s[qb][kt]);
       }
     }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
     const int kv0 = ctile * BC;
     if (kv0 + BC > c_nk) {
 #pragma unroll
@@ -171,6 +173,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn3_kernel(ovg_attn_params p,
         for (int r = 0; r < 4; ++r) s[qb][kt][r] = __builtin_amdgcn_exp2f(s[qb][kt][r]);
     }
     // ---- O^T += V^T P^T ;  l += 1^T P^T ---------------------------------------
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       u32x4 pf[QB];
@@ -187,6 +190,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn3_kernel(ovg_attn_params p,
         for (int qb = 0; qb < QB; ++qb) o[qb][dt] = mma_c<T>(vf, pf[qb], o[qb][dt]);
       }
     }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
     if (++ctile == c_ntiles) {
       ctile = 0; ++cseg;
       if (cseg < p.nseg) { c_nk = (int)p.seg[cseg].nk; c_ntiles = (c_nk + BC - 1) / BC; }
