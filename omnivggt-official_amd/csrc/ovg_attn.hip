@@ -514,36 +514,7 @@ int launch_attn3(const ovg_attn_params& p, hipStream_t st) {
   return OVG_OK;
 }
 
-#include "ovg_attn_v4.h"
-
-template <typename T, int QB>
-int launch_attn4(const ovg_attn_params& p, hipStream_t st) {
-  constexpr int BQ = 64 * QB;
-  const int nqt = (int)((p.nq + BQ - 1) / BQ);
-  int total = 0;
-  for (int i = 0; i < p.nseg; ++i) total += (int)((p.seg[i].nk + BC - 1) / BC);
-  const dim3 grid((unsigned)(p.BH * nqt)), block(256);
-  OVG_LAUNCH((attn4_kernel<T, QB>), grid, block, 0, st, p, nqt, total);
-  OVG_CHECK_LAUNCH();
-  return OVG_OK;
-}
-
-#include "ovg_attn_v5.h"
-
-template <typename T, int QB>
-int launch_attn5(const ovg_attn_params& p, hipStream_t st) {
-  constexpr int BQ = 64 * QB;
-  const int nqt = (int)((p.nq + BQ - 1) / BQ);
-  int total = 0;
-  for (int i = 0; i < p.nseg; ++i) total += (int)((p.seg[i].nk + BC - 1) / BC);
-  const dim3 grid((unsigned)(p.BH * nqt)), block(256);
-  OVG_LAUNCH((attn5_kernel<T, QB>), grid, block, 0, st, p, nqt, total);
-  OVG_CHECK_LAUNCH();
-  return OVG_OK;
-}
-
 // variant: 0 = default choice; 1/2 = baseline kernel QB=1/2; 3/4/5 = attn2 QB=2/4/3;
-// 12/13/14 = attn4 (software-pipelined) QB=4/3/2; 15/16/17 = attn5 (hand-interleaved) QB=4/3/2
 // 6..10 = attn3 (QB,WAVES) = (4,4) (4,2) (2,4) (2,2) (3,4)
 template <typename T>
 int dispatch16(const ovg_attn_params& p, hipStream_t st) {
@@ -561,12 +532,6 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
     case 9: return launch_attn3<T, 2, 2>(p, st);
     case 10: return launch_attn3<T, 3, 4>(p, st);
     case 11: return launch_attn3<T, 4, 4, true>(p, st);   // + s_setprio around the MFMA clusters
-    case 12: return launch_attn4<T, 4>(p, st);
-    case 13: return launch_attn4<T, 3>(p, st);
-    case 14: return launch_attn4<T, 2>(p, st);
-    case 15: return launch_attn5<T, 4>(p, st);
-    case 16: return launch_attn5<T, 3>(p, st);
-    case 17: return launch_attn5<T, 2>(p, st);
     default: return OVG_E_ARG;
   }
 }

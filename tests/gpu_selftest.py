@@ -207,7 +207,7 @@ def test_attn(quick):
     for name, dt in DT.items():
         shapes = [("n1374_bh32", 32, 1374, [1374]), ("n2748_2seg", 16, 2748 // 2, [1374, 1374]),
                   ("n700_ragged_seg", 16, 700, [100, 333, 64]), ("n300_seg", 16, 300, [130, 70])]
-        variants = (1,) if name == "f32" else (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17)   # baseline, attn2, attn3 variants
+        variants = (1,) if name == "f32" else (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11)   # baseline, attn2, attn3 variants
         if quick:
             shapes = shapes[:2]
         for cname, BH, nq, nks in shapes:
@@ -244,7 +244,7 @@ def test_attn(quick):
             qd[:, :nq] = q.to(DEV)
             kd[:, :nk] = k.to(DEV)
             vtd[:, :, :nk] = v.transpose(1, 2).to(DEV)
-            for variant in ((1,) if name == "f32" else (1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17)):
+            for variant in ((1,) if name == "f32" else (1, 3, 4, 5, 6, 7, 8, 9, 10, 11)):
                 out = ops.flash_attn(qd, [(kd, vtd, nk)], nq, dt, variant=variant)
                 report("attn_%s_%s_rescale_v%d" % (name, cname, variant), out, ref, TOL[name])
 
