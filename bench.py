@@ -151,7 +151,8 @@ def main():
                        "parallelism": "view-shard x%d" % world},
             "algorithmic_tflop_per_step": round(f_total / 1e12, 2),
             "tflops_per_gpu": round(f_total / 1e12 / (dt / steps) / world, 1),
-            "roofline": {"bound": "mfma", "kernel": ("attn3_kernel<bf16,QB=4,WAVES=4>" if args.dtype != "f32" else "attn_kernel<float,1>")
+            "roofline": {"bound": "mfma", "kernel": ({"bf16": "attn_spec_kernel<bf16,QB=4,WAVES=4> (speculative anchored softmax + verified fallback)",
+                                                       "f16": "attn3_kernel<f16,QB=4,WAVES=4>"}.get(args.dtype, "attn_kernel<float,1>"))
                          + " (global cross-view attention, D=64)", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": None, "flop_per_launch": launch_flops,
                          "avg_launch_ms": round(attn_avg_ms, 4), "launches_timed": len(attn_ms)},
@@ -175,7 +176,10 @@ def main():
         tr = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tr):
             try:
-                result["roofline"]["traffic"] = json.load(open(tr)).get("global_attn_S%d_bytes_per_launch" % S)
+                traffic = json.load(open(tr))
+                result["roofline"]["traffic"] = traffic.get("global_attn_S%d_bytes_per_launch" % S)
+                if "secondary" in result:
+                    result["secondary"]["roofline"]["traffic"] = traffic.get("global_attn_S8_bytes_per_launch")
             except Exception:
                 pass
         if args.e2e:

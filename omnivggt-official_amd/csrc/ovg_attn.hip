@@ -17,6 +17,7 @@
 // q is pre-scaled by softmax_scale*log2(e): probabilities are exp2(s - m).
 // K/V^T may come as several segments (one per rank of the view-sharded all-gather).
 #include "ovg_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -502,14 +503,28 @@ int launch_attn(const ovg_attn_params& p, hipStream_t st) {
 
 #include "ovg_attn_v3.h"
 
-template <typename T, int QB, int WAVES, bool PRIO = false>
+template <typename T, int QB, int WAVES, bool PRIO = false, int SM = 0>
 int launch_attn3(const ovg_attn_params& p, hipStream_t st) {
   constexpr int BQ = 16 * QB * WAVES;
   const int nqt = (int)((p.nq + BQ - 1) / BQ);
   int total = 0;
   for (int i = 0; i < p.nseg; ++i) total += (int)((p.seg[i].nk + BC - 1) / BC);
   const dim3 grid((unsigned)(p.BH * nqt)), block(64 * WAVES);
-  OVG_LAUNCH((attn3_kernel<T, QB, WAVES, PRIO>), grid, block, 0, st, p, nqt, total);
+  OVG_LAUNCH((attn3_kernel<T, QB, WAVES, PRIO, SM>), grid, block, 0, st, p, nqt, total);
+  OVG_CHECK_LAUNCH();
+  return OVG_OK;
+}
+
+#include "ovg_attn_spec.h"
+
+template <typename T, int QB, int WAVES, int ANCHOR, int DMA, int HALF, bool FORCE = false>
+int launch_attn_spec(const ovg_attn_params& p, hipStream_t st) {
+  constexpr int BQ = 16 * QB * WAVES;
+  const int nqt = (int)((p.nq + BQ - 1) / BQ);
+  int total = 0;
+  for (int i = 0; i < p.nseg; ++i) total += (int)((p.seg[i].nk + BC - 1) / BC);
+  const dim3 grid((unsigned)(p.BH * nqt)), block(64 * WAVES);
+  OVG_LAUNCH((attn_spec_kernel<T, QB, WAVES, ANCHOR, DMA, HALF, FORCE>), grid, block, 0, st, p, nqt, total);
   OVG_CHECK_LAUNCH();
   return OVG_OK;
 }
@@ -519,7 +534,11 @@ int launch_attn3(const ovg_attn_params& p, hipStream_t st) {
 template <typename T>
 int dispatch16(const ovg_attn_params& p, hipStream_t st) {
   int v = p.variant;
-  if (v == 0) v = p.nq >= 4096 ? 6 : 8;   // measured best: attn3 QB=4 for long sequences, QB=2 for 1374
+  // measured best: QB=4 for long sequences, QB=2 for 1374; bf16 takes the speculative anchored-softmax
+  // kernel (exact, see ovg_attn_spec.h), f16 the lazy-rescale attn3 (P would overflow in f16)
+  constexpr bool kBf16 = std::is_same<T, bf16_t>::value;
+  if (v == 0) v = kBf16 ? (p.nq >= 4096 ? 21 : 25) : (p.nq >= 4096 ? 6 : 8);
+  if (!kBf16 && v >= 16) return OVG_E_ARG;
   switch (v) {
     case 1: return launch_attn<T, 1, false>(p, st);
     case 2: return launch_attn<T, 2, false>(p, st);
@@ -532,6 +551,29 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
     case 9: return launch_attn3<T, 2, 2>(p, st);
     case 10: return launch_attn3<T, 3, 4>(p, st);
     case 11: return launch_attn3<T, 4, 4, true>(p, st);   // + s_setprio around the MFMA clusters
+    case 12: return launch_attn3<T, 4, 4, false, 1>(p, st);   // single rescale branch for all q blocks
+    case 13: return launch_attn3<T, 2, 4, false, 1>(p, st);
+    case 14: return launch_attn3<T, 4, 4, false, 2>(p, st);   // EXPERIMENT (not exact in general): no running max at all
+    case 15: return launch_attn3<T, 2, 4, false, 2>(p, st);
+    case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28:
+      if constexpr (kBf16) {   // speculative anchored softmax + verified fallback: <QB, WAVES, ANCHOR, DMA, HALF>
+        switch (v) {
+          case 16: return launch_attn_spec<T, 4, 4, 2, 0, 0>(p, st);
+          case 17: return launch_attn_spec<T, 2, 4, 2, 0, 0>(p, st);
+          case 18: return launch_attn_spec<T, 4, 4, 2, 0, 0, true>(p, st);   // tests: force the fallback recompute
+          case 19: return launch_attn_spec<T, 2, 4, 2, 0, 0, true>(p, st);
+          case 20: return launch_attn_spec<T, 4, 4, 0, 0, 0>(p, st);
+          case 21: return launch_attn_spec<T, 4, 4, 1, 0, 0>(p, st);
+          case 22: return launch_attn_spec<T, 4, 4, 2, 0, 1>(p, st);
+          case 23: return launch_attn_spec<T, 4, 4, 2, 1, 0>(p, st);
+          case 24: return launch_attn_spec<T, 4, 4, 2, 1, 1>(p, st);
+          case 25: return launch_attn_spec<T, 2, 4, 1, 0, 0>(p, st);
+          case 26: return launch_attn_spec<T, 2, 4, 2, 1, 1>(p, st);
+          case 27: return launch_attn_spec<T, 3, 4, 1, 0, 0>(p, st);
+          default: return launch_attn_spec<T, 4, 4, 1, 0, 1>(p, st);
+        }
+      }
+      return OVG_E_ARG;
     default: return OVG_E_ARG;
   }
 }

@@ -202,12 +202,17 @@ def attn_reference(q, k, v):
     return torch.softmax(s, dim=-1) @ v
 
 
+SPEC_VARIANTS = (16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28)   # speculative anchored-softmax kernels (bf16 only)
+
+
 def test_attn(quick):
     g = torch.Generator().manual_seed(5)
     for name, dt in DT.items():
         shapes = [("n1374_bh32", 32, 1374, [1374]), ("n2748_2seg", 16, 2748 // 2, [1374, 1374]),
                   ("n700_ragged_seg", 16, 700, [100, 333, 64]), ("n300_seg", 16, 300, [130, 70])]
-        variants = (1,) if name == "f32" else (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11)   # baseline, attn2, attn3 variants
+        variants = (1,) if name == "f32" else (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)   # default, baseline, attn2, attn3 variants
+        if name == "bf16":
+            variants += SPEC_VARIANTS
         if quick:
             shapes = shapes[:2]
         for cname, BH, nq, nks in shapes:
@@ -230,7 +235,9 @@ def test_attn(quick):
                 report("attn_%s_%s_v%d" % (name, cname, variant), out, ref_tok, TOL[name])
         # forced-rescale cases: one key spikes against one query late in the sequence (the lazy
         # rescale branch of the tuned kernel fires mid-stream), and a slowly rising score ramp
-        for cname, spike in (("spike", 6.0), ("ramp", 0.0)):
+        # (speculative kernel: spike 6 / ramp leave the f32 exponent window -> verified fallback path;
+        #  spike 1 = 64 log2 units above the rest stays inside it)
+        for cname, spike in (("spike", 6.0), ("spike_small", 1.0), ("ramp", 0.0)):
             BH, nq, nk = 16, 128, 640
             q = rnd(BH, nq, 64, g=g).to(dt)
             k = rnd(BH, nk, 64, g=g).to(dt)
@@ -244,7 +251,7 @@ def test_attn(quick):
             qd[:, :nq] = q.to(DEV)
             kd[:, :nk] = k.to(DEV)
             vtd[:, :, :nk] = v.transpose(1, 2).to(DEV)
-            for variant in ((1,) if name == "f32" else (1, 3, 4, 5, 6, 7, 8, 9, 10, 11)):
+            for variant in ((1,) if name == "f32" else (0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13) + (SPEC_VARIANTS if name == "bf16" else ())):
                 out = ops.flash_attn(qd, [(kd, vtd, nk)], nq, dt, variant=variant)
                 report("attn_%s_%s_rescale_v%d" % (name, cname, variant), out, ref, TOL[name])
 
