@@ -259,8 +259,12 @@ int ovg_copy_rows(const ovg_copy_rows_params*, void* stream);
  * acc of one 16x16 MFMA for dtype given raw 16-byte A/B fragments per lane. */
 int ovg_probe_mfma(const void* a_frag, const void* b_frag, float* out, int dtype, void* stream);
 
-/* Benchmarking knob (process-global, not thread-safe, never needed for correctness):
- * key 0 = GEMM tile-order group size (0 = n-fastest, default 8 = grouped, see ovg_gemm.hip). */
+/* Benchmarking knobs (process-global, not thread-safe, never needed for correctness):
+ * key 0 = GEMM tile-order group size of the 128x128 kernels (0 = n-fastest, default 8 = grouped, see ovg_gemm.hip);
+ * key 1 = GEMM main loop: 0 automatic choice between the 128x128 register-staged and the 256x256 ping-pong
+ *         loop (default), 1 = 128x128 LDS-DMA, 2/3 = its diagnostic ablations, 4 = force 256x256 where legal,
+ *         5/6 = its diagnostic ablations, 7 = force 128x128;
+ * key 2 = tile-order group size of the 256x256 kernels (default 4). */
 int ovg_debug_set(int key, int value);
 
 #ifdef __cplusplus

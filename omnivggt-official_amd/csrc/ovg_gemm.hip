@@ -216,24 +216,16 @@ OVG_DEV void gemm_mainloop_glds(const T* __restrict__ X, int64_t ldx, const T* _
 }
 
 // ---------------------------------------------------------------------------
-// Linear kernel (STORE / GELU / RES / PATCH epilogues)
+// Linear epilogues (STORE / GELU / RES / PATCH) on a wave's 64(n) x 16*MT(m) accumulator block:
+// acc[nt][mt] = C[n = n_w0 + 16nt + 4g + r][m = m_w0 + 16mt + (lane&15)]
 // ---------------------------------------------------------------------------
-template <typename T, int EPI, bool OUT_F32, int GLDS>   // GLDS: 0 register-staged, 1 LDS-DMA, 2/3 LDS-DMA ablations
-__global__ __launch_bounds__(256, 2) void linear_kernel(ovg_linear_params p, int ntiles_n) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[(GLDS ? 4 : 2) * 128 * 128];
-  const int M = (int)p.M, N = (int)p.N, K = (int)p.K;
-  int tm, tn;
-  tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + BM - 1) / BM, ntiles_n, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
-  f32x4 acc[4][4];
-  if constexpr (GLDS != 0) gemm_mainloop_glds<T, GLDS - 1>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds, acc);
-  else gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds, acc);
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wn = wave >> 1, wm = wave & 1, g = lane >> 4, lr = lane & 15;
+template <typename T, int EPI, bool OUT_F32, int MT>
+OVG_DEV void linear_epilogue(const ovg_linear_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int n_w0) {
+  const int M = (int)p.M, N = (int)p.N;
+  const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = m0 + wm * 64 + mt * 16 + lr;
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m_w0 + mt * 16 + lr;
     if (m >= M) continue;
     int64_t orow = m;
     int trow = 0;
@@ -246,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(ovg_linear_params p, int
     if constexpr (EPI == OVG_EPI_RES) { inj = (p.inject != nullptr) && (m % (int)p.inj_period == 0); }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      const int n = n0 + wn * 64 + nt * 16 + 4 * g;
+      const int n = n_w0 + nt * 16 + 4 * g;
       f32x4 v = acc[nt][mt];
       if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
       if constexpr (EPI == OVG_EPI_GELU) {
@@ -268,27 +260,32 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(ovg_linear_params p, int
   }
 }
 
-// ---------------------------------------------------------------------------
-// QKV kernel: bias + per-head LayerNorm(64) + 2-D RoPE + q scale, head-major stores
-// ---------------------------------------------------------------------------
-template <typename T, bool GLDS>
-__global__ __launch_bounds__(256, 2) void qkv_kernel(ovg_qkv_params p, int nt_begin, int nt_count) {
+template <typename T, int EPI, bool OUT_F32, int GLDS>   // GLDS: 0 register-staged, 1 LDS-DMA, 2/3 LDS-DMA ablations
+__global__ __launch_bounds__(256, 2) void linear_kernel(ovg_linear_params p, int ntiles_n) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[(GLDS ? 4 : 2) * 128 * 128];
-  constexpr int N = 3 * OVG_C, K = OVG_C;
-  const int M = (int)p.M;
+  const int M = (int)p.M, N = (int)p.N, K = (int)p.K;
   int tm, tn;
-  tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + BM - 1) / BM, nt_count, tm, tn);   // nt_count carries GM in its high half
-  const int m0 = tm * BM, n0 = (nt_begin + tn) * BN;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + BM - 1) / BM, ntiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
   f32x4 acc[4][4];
-  if constexpr (GLDS) gemm_mainloop_glds<T, 0>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
-  else gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
+  if constexpr (GLDS != 0) gemm_mainloop_glds<T, GLDS - 1>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds, acc);
+  else gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds, acc);
+  const int wave = threadIdx.x >> 6;
+  linear_epilogue<T, EPI, OUT_F32, 4>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64);
+}
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wn = wave >> 1, wm = wave & 1, g = lane >> 4, lr = lane & 15;
-  const int which = n0 / OVG_C;                         // 0 q, 1 k, 2 v (uniform per block)
-  const int h = ((n0 % OVG_C) + wn * 64) / OVG_D;       // head of this wave's 64 columns
-  const int ncol0 = n0 + wn * 64;
+// ---------------------------------------------------------------------------
+// QKV epilogue on a wave's 64(n) x 16*MT(m) block (64 columns = one head of q, k or v):
+// bias + per-head LayerNorm(64) + 2-D RoPE + q scale, head-major stores, V transposed
+// ---------------------------------------------------------------------------
+template <typename T, int MT>
+OVG_DEV void qkv_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int ncol0_) {
+  const int ncol0 = __builtin_amdgcn_readfirstlane(ncol0_);   // wave-uniform: keep the q/k/v dispatch scalar
+  const int M = (int)p.M;
+  const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
   const int seq = (int)p.seq;
+  const int which = ncol0 / OVG_C;                      // 0 q, 1 k, 2 v (uniform per wave)
+  const int h = (ncol0 % OVG_C) / OVG_D;                // head of this wave's 64 columns
 
   float bias[16];
 #pragma unroll
@@ -311,8 +308,8 @@ __global__ __launch_bounds__(256, 2) void qkv_kernel(ovg_qkv_params p, int nt_be
   }
 
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = m0 + wm * 64 + mt * 16 + lr;
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m_w0 + mt * 16 + lr;
     const bool valid = m < M;
     float v[16];
 #pragma unroll
@@ -375,11 +372,64 @@ __global__ __launch_bounds__(256, 2) void qkv_kernel(ovg_qkv_params p, int nt_be
   }
 }
 
+template <typename T, bool GLDS>
+__global__ __launch_bounds__(256, 2) void qkv_kernel(ovg_qkv_params p, int nt_begin, int nt_count) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(GLDS ? 4 : 2) * 128 * 128];
+  constexpr int N = 3 * OVG_C, K = OVG_C;
+  const int M = (int)p.M;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + BM - 1) / BM, nt_count, tm, tn);   // nt_count carries GM in its high half
+  const int m0 = tm * BM, n0 = (nt_begin + tn) * BN;
+  f32x4 acc[4][4];
+  if constexpr (GLDS) gemm_mainloop_glds<T, 0>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
+  else gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
+  const int wave = threadIdx.x >> 6;
+  qkv_epilogue<T, 4>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64);
+}
+
+#include "ovg_gemm256.h"
+
+// 256 x 256 ping-pong variants (16-bit modes): same epilogues on acc[4][8]
+template <typename T, int EPI, bool OUT_F32, int ABL = 0>
+__global__ __launch_bounds__(512) void linear256_kernel(ovg_linear_params p, int ntiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds256[];
+  const int M = (int)p.M, N = (int)p.N, K = (int)p.K;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + g256::BM2 - 1) / g256::BM2, ntiles_n, tm, tn);
+  const int m0 = tm * g256::BM2, n0 = tn * g256::BN2;
+  f32x4 acc[4][8];
+  g256::mainloop<T, ABL>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds256, acc);
+  const int wave = threadIdx.x >> 6;
+  linear_epilogue<T, EPI, OUT_F32, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64);
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void qkv256_kernel(ovg_qkv_params p, int nt_begin, int nt_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds256[];
+  constexpr int N = 3 * OVG_C, K = OVG_C;
+  const int M = (int)p.M;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + g256::BM2 - 1) / g256::BM2, nt_count, tm, tn);
+  const int m0 = tm * g256::BM2, n0 = (nt_begin + tn) * g256::BN2;
+  f32x4 acc[4][8];
+  g256::mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds256, acc);
+  const int wave = threadIdx.x >> 6;
+  qkv_epilogue<T, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64);
+}
+
+template <typename KernelT>
+int allow_big_lds(KernelT kernel) {     // once per kernel: opt in to > 64 KB of dynamic LDS
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, g256::LDS_BYTES) == hipSuccess ? OVG_OK : OVG_E_LAUNCH;
+}
+
 int g_tile_group = 8;   // ovg_debug_set(0, v): tile-order group size (benchmarking knob)
+int g_tile_group256 = 4; // ovg_debug_set(2, v): same for the 256 x 256 kernels
+int g_mainloop = 0;     // ovg_debug_set(1, v): 0 = auto (128^2 register-staged or 256^2 ping-pong), 1 = LDS-DMA 128^2, 2/3 ablations,
+                        // 4 = force 256^2 ping-pong, 5/6 its ablations, 7 = force 128^2 register-staged
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-int g_mainloop = 0;     // ovg_debug_set(1, v): 0 = register-staged main loop, 1 = LDS-DMA (global_load_lds)
+
 
 template <typename T, int GLDS>
 int launch_linear_ml(const ovg_linear_params& p, hipStream_t st) {
@@ -405,10 +455,53 @@ int launch_linear_ml(const ovg_linear_params& p, hipStream_t st) {
   OVG_CHECK_LAUNCH();
   return OVG_OK;
 }
+template <typename T, int EPI, bool OUT_F32, int ABL = 0>
+int launch_linear256_one(const ovg_linear_params& p, hipStream_t st) {
+  static const int ok = allow_big_lds(linear256_kernel<T, EPI, OUT_F32, ABL>);
+  if (ok != OVG_OK) return ok;
+  const int mt = (int)((p.M + g256::BM2 - 1) / g256::BM2), nt = (int)(p.N / g256::BN2);
+  const int ntg = nt | (g_tile_group256 << 16);
+  OVG_LAUNCH((linear256_kernel<T, EPI, OUT_F32, ABL>), dim3(mt * nt), dim3(512), g256::LDS_BYTES, st, p, ntg);
+  OVG_CHECK_LAUNCH();
+  return OVG_OK;
+}
+template <typename T>
+int launch_linear256(const ovg_linear_params& p, hipStream_t st) {
+  switch (p.epilogue) {
+    case OVG_EPI_STORE: return p.out_f32 ? launch_linear256_one<T, OVG_EPI_STORE, true>(p, st) : launch_linear256_one<T, OVG_EPI_STORE, false>(p, st);
+    case OVG_EPI_GELU: return launch_linear256_one<T, OVG_EPI_GELU, false>(p, st);
+    case OVG_EPI_RES:
+      if (g_mainloop == 5) return launch_linear256_one<T, OVG_EPI_RES, true, 1>(p, st);   // diagnostic: no DMA in the loop
+      if (g_mainloop == 6) return launch_linear256_one<T, OVG_EPI_RES, true, 2>(p, st);   // diagnostic: no MFMAs
+      return launch_linear256_one<T, OVG_EPI_RES, true>(p, st);
+    case OVG_EPI_PATCH: return launch_linear256_one<T, OVG_EPI_PATCH, true>(p, st);
+    default: return OVG_E_ARG;
+  }
+}
+// Tile choice for the 16-bit modes (measured, tests/bench_kernels.py gemm --mainloops 0 4, profiles/r01_gemm256_ab.txt):
+// the 256 x 256 ping-pong loop wins by 9-14 % on QKV / fc1 / fc2 once its tiles fill the 256 CUs evenly, and
+// loses on the proj GEMM (K = 1024 with the f32 residual epilogue: one workgroup per CU cannot overlap that
+// epilogue with another workgroup's main loop) and on badly quantised grids (QKV at M = 10 992: 516 tiles =
+// 2.02 rounds). g_mainloop: 0 = this automatic choice, 1 = 128^2 LDS-DMA, 4 = force 256^2, 7 = force 128^2.
+bool use_256(int64_t M, int64_t N, int64_t K, bool light_epilogue_or_long_k) {
+  if (N % g256::BN2 != 0 || K % 32 != 0) return false;
+  if (g_mainloop >= 4 && g_mainloop <= 6) return true;
+  if (g_mainloop != 0) return false;
+  // in situ (bench.py, whole forward) the 256^2 kernels only pay off for long token slices: at M = 10 992 the
+  // forward is 2 % faster with 128^2 everywhere, at M = 87 936 it is 2 % faster with this choice
+  if (!light_epilogue_or_long_k || M < 32768) return false;
+  const int64_t tiles = ((M + g256::BM2 - 1) / g256::BM2) * (N / g256::BN2);
+  const int64_t rounds = (tiles + 255) / 256;
+  return tiles * 100 >= rounds * 256 * 80 || K >= 2048;   // >= 80 % of the last round's CUs busy
+}
+
 template <typename T>
 int launch_linear(const ovg_linear_params& p, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    if (use_256(p.M, p.N, p.K, p.epilogue != OVG_EPI_RES || p.K >= 2048)) return launch_linear256<T>(p, st);
+  }
   if constexpr (sizeof(T) == 2) {           // ablation builds exist for the bf16/f16 RES epilogue only
-    if (g_mainloop >= 2 && p.epilogue == OVG_EPI_RES) {
+    if ((g_mainloop == 2 || g_mainloop == 3) && p.epilogue == OVG_EPI_RES) {
       const int mt = (int)((p.M + BM - 1) / BM), nt = (int)(p.N / BN);
       const int ntg = nt | (g_tile_group << 16);
       if (g_mainloop == 2) OVG_LAUNCH((linear_kernel<T, OVG_EPI_RES, true, 2>), dim3(mt * nt), dim3(256), 0, st, p, ntg);
@@ -465,6 +558,24 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
   const int nt_count = p->part == 0 ? all_tiles : (p->part == 1 ? all_tiles - q_tiles : q_tiles);
   const dim3 grid((unsigned)(((p->M + BM - 1) / BM) * nt_count)), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (p->dtype != OVG_F32 && use_256(p->M, (p->part == 0 ? 3 : (p->part == 1 ? 2 : 1)) * OVG_C, OVG_C, true)) {
+    const int q_t = OVG_C / g256::BN2, all_t = 3 * OVG_C / g256::BN2;
+    const int ntb = p->part == 1 ? q_t : 0;
+    const int ntc = p->part == 0 ? all_t : (p->part == 1 ? all_t - q_t : q_t);
+    const dim3 grid2((unsigned)(((p->M + g256::BM2 - 1) / g256::BM2) * ntc));
+    const int ntg2 = ntc | (g_tile_group256 << 16);
+    if (p->dtype == OVG_BF16) {
+      static const int ok = allow_big_lds(qkv256_kernel<bf16_t>);
+      if (ok != OVG_OK) return ok;
+      OVG_LAUNCH((qkv256_kernel<bf16_t>), grid2, dim3(512), g256::LDS_BYTES, st, *p, ntb, ntg2);
+    } else {
+      static const int ok = allow_big_lds(qkv256_kernel<f16_t>);
+      if (ok != OVG_OK) return ok;
+      OVG_LAUNCH((qkv256_kernel<f16_t>), grid2, dim3(512), g256::LDS_BYTES, st, *p, ntb, ntg2);
+    }
+    OVG_CHECK_LAUNCH();
+    return OVG_OK;
+  }
   const int ntg = nt_count | (g_tile_group << 16);
   switch (p->dtype) {
     case OVG_BF16: if (g_mainloop == 1) OVG_LAUNCH((qkv_kernel<bf16_t, true>), grid, block, 0, st, *p, nt_begin, ntg); else OVG_LAUNCH((qkv_kernel<bf16_t, false>), grid, block, 0, st, *p, nt_begin, ntg); break;
@@ -478,6 +589,7 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
 
 extern "C" int ovg_debug_set(int key, int value) {
   if (key == 0 && value >= 0 && value < 256) { g_tile_group = value; return OVG_OK; }
-  if (key == 1 && value >= 0 && value <= 3) { g_mainloop = value; return OVG_OK; }
+  if (key == 1 && value >= 0 && value <= 7) { g_mainloop = value; return OVG_OK; }
+  if (key == 2 && value >= 0 && value < 256) { g_tile_group256 = value; return OVG_OK; }
   return OVG_E_ARG;
 }

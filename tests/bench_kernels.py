@@ -95,15 +95,18 @@ def gemm(args):
             fn()
             combos = [(gm, ml) for gm in args.tile_groups for ml in args.mainloops]
             if args.ablate:
-                combos = [(8, 0), (8, 1), (8, 2), (8, 3)]        # 2/3 = LDS-DMA loop without loads / without MFMAs (RES epilogue only)
+                # 2/3 = 128^2 LDS-DMA loop without loads / without MFMAs; 5/6 = the same for the 256^2 ping-pong loop (RES epilogue only)
+                combos = [(8, 7), (8, 1), (8, 2), (8, 3), (4, 4), (4, 5), (4, 6)]
             ts = {c: [] for c in combos}
             for _ in range(args.rounds):
                 for gm, ml in combos:                  # interleaved A/B of the tuning knobs
                     L.load().ovg_debug_set(0, gm)
+                    L.load().ovg_debug_set(2, gm if ml >= 4 else 4)     # 256^2 kernels: their own group size
                     L.load().ovg_debug_set(1, ml)
                     ts[(gm, ml)].append(timed(fn, 20))
             L.load().ovg_debug_set(0, 8)
             L.load().ovg_debug_set(1, 0)
+            L.load().ovg_debug_set(2, 4)
             for gm, ml in combos:
                 ms = statistics.median(ts[(gm, ml)])
                 tf = 2.0 * M * N * K / ms / 1e9
@@ -121,7 +124,7 @@ def main():
     ap.add_argument("--modes", nargs="+", default=["global", "frame"])
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--tile-groups", type=int, nargs="+", default=[8])
-    ap.add_argument("--mainloops", type=int, nargs="+", default=[0], help="0 = register-staged, 1 = LDS-DMA")
+    ap.add_argument("--mainloops", type=int, nargs="+", default=[0], help="0 = automatic, 7 = 128^2 register-staged, 1 = 128^2 LDS-DMA, 4 = 256^2 ping-pong")
     ap.add_argument("--ablate", action="store_true", help="GEMM: also time the LDS-DMA loop without loads / without MFMAs")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--target-ms", type=float, default=20.0)
