@@ -555,7 +555,7 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
     case 13: return launch_attn3<T, 2, 4, false, 1>(p, st);
     case 14: return launch_attn3<T, 4, 4, false, 2>(p, st);   // EXPERIMENT (not exact in general): no running max at all
     case 15: return launch_attn3<T, 2, 4, false, 2>(p, st);
-    case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37:
+    case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28:
       if constexpr (kBf16) {   // speculative anchored softmax + verified fallback: <QB, WAVES, ANCHOR, DMA, HALF>
         switch (v) {
           case 16: return launch_attn_spec<T, 4, 4, 2, 0, 0>(p, st);
@@ -570,16 +570,7 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
           case 25: return launch_attn_spec<T, 2, 4, 1, 0, 0>(p, st);
           case 26: return launch_attn_spec<T, 2, 4, 2, 1, 1>(p, st);
           case 27: return launch_attn_spec<T, 3, 4, 1, 0, 0>(p, st);
-          case 28: return launch_attn_spec<T, 4, 4, 1, 0, 1>(p, st);
-          case 29: return launch_attn_spec<T, 4, 4, 1, 0, 2>(p, st);
-          case 30: return launch_attn_spec<T, 2, 4, 1, 0, 2>(p, st);
-          case 31: return launch_attn_spec<T, 4, 4, 2, 0, 2>(p, st);
-          case 32: return launch_attn_spec<T, 4, 4, 1, 1, 2>(p, st);
-          case 33: return launch_attn_spec<T, 4, 4, 2, 1, 2>(p, st);
-          case 34: return launch_attn_spec<T, 4, 4, 0, 0, 2>(p, st);
-          case 35: return launch_attn_spec<T, 4, 4, 0, 1, 2>(p, st);
-          case 36: return launch_attn_spec<T, 3, 4, 1, 0, 2>(p, st);
-          default: return launch_attn_spec<T, 3, 4, 1, 1, 2>(p, st);   // 37
+          default: return launch_attn_spec<T, 4, 4, 1, 0, 1>(p, st);
         }
       }
       return OVG_E_ARG;

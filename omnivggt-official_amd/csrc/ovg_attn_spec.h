@@ -25,8 +25,7 @@
 //          registers instead of 4 QB for the C operand)
 //   DMA    0 register-staged K / V^T tiles, V^T written key-permuted (b128 fragment reads)
 //          1 LDS-DMA (global_load_lds_dwordx4), V^T in natural key order (two b64 reads per fragment)
-//   HALF   0 one 64-key body | 1 two 32-key halves (half of S' live at a time) | 2 two halves software-
-//          pipelined (exp of one half beside the MFMAs of the other, sched_group_barrier pattern)
+//   HALF   0 one 64-key body | 1 two 32-key halves (half of S' live at a time)
 #pragma once
 
 namespace spec {
@@ -232,16 +231,6 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
       for (int kt = 0; kt < 4; ++kt) mask_kt(s[kt], kv0, kt);
     }
   };
-  auto pv_mma = [&](const unsigned char* vl, int u, const u32x4 (&pf)[QB]) {
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) lacc[qb] = mma_c<T>(ones, pf[qb], lacc[qb]);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const u32x4 vf = vfrag(vl, u, dt);
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) o[qb][dt] = mma_c<T>(vf, pf[qb], o[qb][dt]);
-    }
-  };
   auto pv_step = [&](const unsigned char* vl, int u, const f32x4 (&sa)[QB], const f32x4 (&sb)[QB]) {
     u32x4 pf[QB];
 #pragma unroll
@@ -297,59 +286,7 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
       // purpose: as ONE basic block hipcc interleaves the whole tile body, stretches the live ranges
       // and spills Q around the loop (the reload's vmcnt(0) then serialises the K/V prefetch)
       const bool tail = kv0 + BC > c_nk;
-      if constexpr (HALF == 2) {
-        // software pipeline inside the tile: the exponentials of one 32-key half run beside the MFMAs of
-        // the other half; sched_group_barrier asks for 1 MFMA : 2 v_exp : 1 v_cvt_pk per slot, and
-        // sched_barrier fences keep the four regions apart (the ragged last tile of a segment takes
-        // its own copy of the body so that the common one has no branch to sink code across)
-        auto body = [&](auto tailtag) {
-          constexpr bool TAIL = decltype(tailtag)::value;
-          f32x4 sA[2][QB], sB[2][QB];
-          u32x4 pA[QB], pB[QB];
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {                       // region 1: S'(A)
-            u32x4 k0, k1;
-            kfrag(kl, h, k0, k1);
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) sA[h][qb] = qk_mma(k0, k1, qb);
-          }
-          if constexpr (TAIL) { mask_kt(sA[0], kv0, 0); mask_kt(sA[1], kv0, 1); }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {                       // region 2: S'(B)  ||  exp / pack (A)
-            u32x4 k0, k1;
-            kfrag(kl, 2 + h, k0, k1);
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) sB[h][qb] = qk_mma(k0, k1, qb);
-          }
-          exp_blk(sA[0]);
-          exp_blk(sA[1]);
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb) pA[qb] = pack2<T>(sA[0][qb], sA[1][qb]);
-#pragma unroll
-          for (int i = 0; i < 4 * QB; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-          }
-          if constexpr (TAIL) { mask_kt(sB[0], kv0, 2); mask_kt(sB[1], kv0, 3); }
-          __builtin_amdgcn_sched_barrier(0);
-          pv_mma(vl, 0, pA);                                  // region 3: O += V P(A)  ||  exp / pack (B)
-          exp_blk(sB[0]);
-          exp_blk(sB[1]);
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb) pB[qb] = pack2<T>(sB[0][qb], sB[1][qb]);
-#pragma unroll
-          for (int i = 0; i < 4 * QB; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-            __builtin_amdgcn_sched_group_barrier(0x400, 2, 1);
-            __builtin_amdgcn_sched_group_barrier(0x002, 1, 1);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          pv_mma(vl, 1, pB);                                  // region 4: O += V P(B)
-        };
-        if (tail) body(Tag<true>{}); else body(Tag<false>{});
-      } else if constexpr (HALF == 1) {
+      if constexpr (HALF) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           f32x4 s2[2][QB];

@@ -202,7 +202,7 @@ def attn_reference(q, k, v):
     return torch.softmax(s, dim=-1) @ v
 
 
-SPEC_VARIANTS = tuple(range(16, 38))   # speculative anchored-softmax kernels (bf16 only)
+SPEC_VARIANTS = (16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28)   # speculative anchored-softmax kernels (bf16 only)
 
 
 def test_attn(quick):
