@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define OVG_ABI_VERSION 1
+/* 2: + DPT-head entries (ovg_head_layernorm, ovg_conv, ovg_upsample, ovg_dpt_out) */
+#define OVG_ABI_VERSION 2
 
 enum { OVG_BF16 = 0, OVG_F16 = 1, OVG_F32 = 2 };
 
@@ -254,6 +255,76 @@ typedef struct {
   const float* x; int64_t ldx; float* y; int64_t ldy; int64_t rows; int64_t n;
 } ovg_copy_rows_params;
 int ovg_copy_rows(const ovg_copy_rows_params*, void* stream);
+
+/* ================================================================== *
+ * DPT dense-prediction head (reference heads/dpt_head.py:185-304,
+ * heads/head_act.py:61-125).  16-bit modes only (OVG_BF16 / OVG_F16, f32 accumulate); the f32
+ * parity mode keeps the PyTorch head.  Activations are NHWC: [n_img, H, W, C] with a pixel
+ * stride (ld, in elements) >= C.
+ * ================================================================== */
+
+/* LayerNorm over rows of 2048 of the aggregator output list (dpt_head.py:219 `self.norm`):
+ * input row of output row r is x + ((r / p0) * p1 + row_off + r % p0) * ldx  (p0 patch tokens kept
+ * per view out of p1 tokens per view, skipping the row_off special tokens); y is [rows, 2048] dtype. */
+typedef struct {
+  const float* x; int64_t ldx;
+  void* y; int64_t ldy;
+  const float* weight; const float* bias;
+  int64_t rows; int64_t p0; int64_t p1; int64_t row_off;
+  float eps; int dtype;
+} ovg_head_layernorm_params;
+int ovg_head_layernorm(const ovg_head_layernorm_params*, void* stream);
+
+/* NHWC convolution as an implicit GEMM on the MFMA (nn.Conv2d k=1 / k=3 stride 1|2 pad k/2, and
+ * nn.ConvTranspose2d with kernel == stride via `upshuffle`; dpt_head.py:221-240 projects /
+ * resize_layers, :274-304 scratch convs, :357-399 ResidualConvUnit, :445-470 FeatureFusionBlock):
+ *   y[i, oy, ox, co] = act( sum_{ky,kx,ci} x[i, oy*stride+ky-pad, ox*stride+kx-pad, ci] * w[co][(ky*k+kx)*Cin + ci]
+ *                           + bias[co] + pos(ox, oy, co) + add1[i,oy,ox,co] + add2[i,oy,ox,co] )
+ *   x  [n_img, H, W, Cin]  (ldx);   w [Cout_gemm, k*k*Cin] dtype, taps-major then channels;   bias f32 or NULL
+ *   pos_x [OW, Cout/2], pos_y [OH, Cout/2] f32 or both NULL: the UV position embedding of dpt_head.py:262-272
+ *         (channels [0, Cout/2) depend on ox only, [Cout/2, Cout) on oy only)
+ *   add1 / add2: optional tensors in output geometry and dtype (ld1 / ld2) -- residual / skip sums
+ *   relu != 0: clamp at 0 after all additions (the in-place ReLU that opens every ResidualConvUnit is folded
+ *         into the producer of its input)
+ *   upshuffle = s > 1 (requires ksize == 1, stride == 1): ConvTranspose2d(k = s, stride = s); w is
+ *         [s*s*Cout, Cin] ordered (dy, dx, co), bias is [Cout]; GEMM row (i, oy, ox), column (dy, dx, co)
+ *         is stored at y[i, oy*s+dy, ox*s+dx, co].  pos / add are not supported together with upshuffle.
+ *   out_f32 != 0: y is f32.
+ * Constraints: Cin % 64 == 0; w holds w_rows rows (a multiple of 128, zero rows beyond the Cout_gemm real ones,
+ * Cout_gemm = Cout, or s*s*Cout with upshuffle: then it must itself be the multiple of 128); Cout % 4 == 0. */
+typedef struct {
+  const void* x; int64_t ldx;
+  const void* w; const float* bias;
+  void* y; int64_t ldy;
+  const void* add1; int64_t ld1; const void* add2; int64_t ld2;
+  const float* pos_x; const float* pos_y;
+  int64_t n_img; int H; int W; int Cin; int Cout; int w_rows; int ksize; int stride; int upshuffle;
+  int relu; int out_f32; int dtype;
+} ovg_conv_params;
+int ovg_conv(const ovg_conv_params*, void* stream);
+
+/* Bilinear resize, align_corners = True (F.interpolate at dpt_head.py:242-247, :466), NHWC, C % 8 == 0:
+ * y[i, oy, ox, :] = lerp of x[i, :, :, :] at (oy*(H-1)/(OH-1), ox*(W-1)/(OW-1)), plus the optional UV
+ * position embedding (pos_x [OW, C/2], pos_y [OH, C/2], dpt_head.py:249-250) -- both in `dtype`. */
+typedef struct {
+  const void* x; int64_t ldx; void* y; int64_t ldy;
+  const float* pos_x; const float* pos_y;
+  int64_t n_img; int H; int W; int OH; int OW; int C; int dtype;
+} ovg_upsample_params;
+int ovg_upsample(const ovg_upsample_params*, void* stream);
+
+/* Output stage of the DPT head (second half of scratch.output_conv2, dpt_head.py:252-258, and
+ * head_act.py:61-125): conv1x1(32 -> out_dim) + activation on the ReLU'd 32-channel map that
+ * ovg_conv (k = 3, Cout = 32, relu, out_f32) produced; f32 in, f32 out:
+ *   activation 0 = "exp" (depth head, out_dim 2: val = exp(v0)), 1 = "inv_log" (point head, out_dim 4:
+ *   val_j = sign(v_j) * expm1(|v_j|), j < 3); confidence = 1 + exp(v_last) ("expp1") in both.
+ *   h [npix, 32] f32;  w2 [out_dim, 32] f32, b2 [out_dim] f32;  val [npix, out_dim-1] f32;  conf [npix] f32 */
+typedef struct {
+  const float* h; const float* w2; const float* b2;
+  float* val; float* conf;
+  int64_t npix; int out_dim; int activation;
+} ovg_dpt_out_params;
+int ovg_dpt_out(const ovg_dpt_out_params*, void* stream);
 
 /* MFMA lane-map probe (diagnostics; tools/selftest.py): fills out[64*4] with
  * acc of one 16x16 MFMA for dtype given raw 16-byte A/B fragments per lane. */

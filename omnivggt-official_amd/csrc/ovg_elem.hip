@@ -290,4 +290,6 @@ extern "C" int ovg_probe_mfma(const void* a, const void* b, float* out, int dtyp
 }
 
 extern "C" int ovg_abi_version(void) { return OVG_ABI_VERSION; }
-extern "C" const char* ovg_build_info(void) { return "libomnivggt_hip gfx950 abi=1 " __DATE__ " " __TIME__; }
+#define OVG_STR2(x) #x
+#define OVG_STR(x) OVG_STR2(x)
+extern "C" const char* ovg_build_info(void) { return "libomnivggt_hip gfx950 abi=" OVG_STR(OVG_ABI_VERSION) " " __DATE__ " " __TIME__; }

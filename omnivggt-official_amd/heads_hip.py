@@ -1,0 +1,158 @@
+"""DPT dense-prediction head on the gfx950 HIP kernels.
+
+`HipDPTHead(dpt_head_module)` runs the forward of `heads.DPTHead` (reference heads/dpt_head.py:128-304) on
+the `ovg_head_layernorm` / `ovg_conv` / `ovg_upsample` / `ovg_dpt_out` entries of libomnivggt_hip.so:
+NHWC 16-bit activations, every convolution an implicit GEMM on the MFMA with bias / ReLU / residual /
+skip / UV-position-embedding / ConvTranspose pixel scatter folded into its epilogue. The parameters
+stay in the wrapped `DPTHead` (same state-dict keys); they are re-packed (NHWC tap order, 16-bit) on
+first use per device / dtype.
+
+Used by `OmniVGGT` when the compute dtype is bf16 / f16; the f32 parity mode keeps the PyTorch head.
+Differences from the reference's arithmetic (all exact in real arithmetic, measured in the tests):
+  * the 1x1 `out_conv` of each fusion block runs BEFORE the bilinear upsampling instead of after
+    (both are linear and the interpolation weights sum to one): 4x fewer FLOPs;
+  * the in-place ReLU that opens every ResidualConvUnit (dpt_head.py:379-399) is applied by the
+    producer of that unit's input.
+"""
+import torch
+
+from . import ops
+from .heads import uv_position_embedding
+
+
+def _taps_major(w):
+    """Conv2d weight [co, ci, kh, kw] -> [co, kh*kw*ci] (tap-major, channels innermost: NHWC implicit GEMM)."""
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+
+
+def _pad_rows(w, mult=128):
+    rows = (w.shape[0] + mult - 1) // mult * mult
+    if rows == w.shape[0]:
+        return w
+    out = torch.zeros(rows, w.shape[1], dtype=w.dtype, device=w.device)
+    out[: w.shape[0]] = w
+    return out
+
+
+def uv_tables(ch, ph, pw, W, H, device):
+    """Separable form of uv_position_embedding: (pos_x [pw, ch/2], pos_y [ph, ch/2]) f32."""
+    emb = uv_position_embedding(torch.zeros(1, ch, ph, pw), W, H)[0]          # [ch, ph, pw] on CPU, exact
+    half = ch // 2
+    pos_x = emb[:half, 0, :].t().contiguous()
+    pos_y = emb[half:, :, 0].t().contiguous()
+    return pos_x.to(device), pos_y.to(device)
+
+
+class HipDPTHead:
+    def __init__(self, head):
+        self.head = head
+        self._packed = None
+        self._key = None
+        self._pos = {}
+
+    # -- weights ---------------------------------------------------------------------------------
+    def _pack(self, dtype, device):
+        h, sc = self.head, self.head.scratch
+        cv = lambda w: w.detach().to(device=device, dtype=dtype).contiguous()
+        f32 = lambda t: None if t is None else t.detach().to(device=device, dtype=torch.float32).contiguous()
+        P = {"norm_w": f32(h.norm.weight), "norm_b": f32(h.norm.bias)}
+        P["proj"] = [(cv(_taps_major(m.weight)), f32(m.bias)) for m in h.projects]
+        r0, r1, r3 = h.resize_layers[0], h.resize_layers[1], h.resize_layers[3]
+        # ConvTranspose2d weight [ci, co, kh, kw] -> rows (dy, dx, co), columns ci
+        P["up0"] = (cv(r0.weight.permute(2, 3, 1, 0).reshape(-1, r0.weight.shape[0])), f32(r0.bias))
+        P["up1"] = (cv(r1.weight.permute(2, 3, 1, 0).reshape(-1, r1.weight.shape[0])), f32(r1.bias))
+        P["down3"] = (cv(_taps_major(r3.weight)), f32(r3.bias))
+        P["rn"] = [cv(_taps_major(getattr(sc, "layer%d_rn" % (i + 1)).weight)) for i in range(4)]
+
+        def rcu(m):
+            return (cv(_taps_major(m.conv1.weight)), f32(m.conv1.bias), cv(_taps_major(m.conv2.weight)), f32(m.conv2.bias))
+
+        P["fusion"] = {}
+        for i in (1, 2, 3, 4):
+            f = getattr(sc, "refinenet%d" % i)
+            P["fusion"][i] = {"out": (cv(_taps_major(f.out_conv.weight)), f32(f.out_conv.bias)),
+                              "rcu1": rcu(f.resConfUnit1) if f.with_skip else None, "rcu2": rcu(f.resConfUnit2)}
+        P["oc1"] = (cv(_taps_major(sc.output_conv1.weight)), f32(sc.output_conv1.bias))
+        c2a, c2b = sc.output_conv2[0], sc.output_conv2[2]
+        P["oc2a"] = (cv(_pad_rows(_taps_major(c2a.weight))), f32(c2a.bias))
+        P["oc2b"] = (f32(c2b.weight.reshape(c2b.weight.shape[0], -1)), f32(c2b.bias))
+        return P
+
+    def _weights(self, dtype, device):
+        # parameter versions: load_state_dict / .to() / in-place edits of the wrapped module invalidate the pack
+        key = (dtype, str(device), tuple((q.data_ptr(), q._version) for q in self.head.parameters()))
+        if self._key != key:
+            self._packed, self._key = self._pack(dtype, device), key
+        return self._packed
+
+    def repack(self):
+        """Call after loading new parameters into the wrapped module."""
+        self._key = None
+
+    def _postab(self, ch, ph, pw, W, H, device):
+        key = (ch, ph, pw, W, H, str(device))
+        if key not in self._pos:
+            self._pos[key] = uv_tables(ch, ph, pw, W, H, device)
+        return self._pos[key]
+
+    # -- forward ---------------------------------------------------------------------------------
+    def __call__(self, aggregated_tokens_list, images, patch_start_idx, frames_chunk_size=8, dtype=torch.bfloat16):
+        B, S, _, H, W = images.shape
+        step = S if (not frames_chunk_size or frames_chunk_size >= S) else frames_chunk_size
+        vals, confs = [], []
+        for b in range(B):
+            pv, pc = [], []
+            for s0 in range(0, S, step):
+                v, c = self._chunk(aggregated_tokens_list, b, s0, min(s0 + step, S), H, W, patch_start_idx, dtype)
+                pv.append(v)
+                pc.append(c)
+            vals.append(torch.cat(pv, 0) if len(pv) > 1 else pv[0])
+            confs.append(torch.cat(pc, 0) if len(pc) > 1 else pc[0])
+        return torch.stack(vals, 0), torch.stack(confs, 0)
+
+    def _rcu(self, w, x, dtype, add2=None, relu_out=False):
+        """ResidualConvUnit on an already ReLU'd input x: conv2(relu(conv1(x))) + x (+ add2) (ReLU'd if relu_out)."""
+        w1, b1, w2, b2 = w
+        t = ops.conv(x, w1, b1, dtype, 256, ksize=3, relu=True)
+        return ops.conv(t, w2, b2, dtype, 256, ksize=3, add1=x, add2=add2, relu=relu_out)
+
+    def _chunk(self, toks, b, s0, s1, H, W, start, dtype):
+        head = self.head
+        n, ps = s1 - s0, head.patch_size
+        ph, pw = H // ps, W // ps
+        dev = toks[0].device
+        P = self._weights(dtype, dev)
+        oc = [m.weight.shape[0] for m in head.projects]
+        pyramid = []
+        for i, layer in enumerate(head.intermediate_layer_idx):
+            t = toks[layer][b, s0:s1]                                   # [n, tokens, 2C] f32 view
+            tpv = t.shape[1]
+            x = ops.head_layernorm(t.reshape(n * tpv, t.shape[2]), P["norm_w"], P["norm_b"], head.norm.eps, dtype, n,
+                                   tokens_per_view=tpv, n_special=start)
+            x = x.view(n, ph, pw, -1)
+            w, bias = P["proj"][i]
+            x = ops.conv(x, w, bias, dtype, oc[i], ksize=1, pos=self._postab(oc[i], ph, pw, W, H, dev))
+            if i == 0:
+                x = ops.conv(x, P["up0"][0], P["up0"][1], dtype, oc[0], ksize=1, upshuffle=4)
+            elif i == 1:
+                x = ops.conv(x, P["up1"][0], P["up1"][1], dtype, oc[1], ksize=1, upshuffle=2)
+            elif i == 3:
+                x = ops.conv(x, P["down3"][0], P["down3"][1], dtype, oc[3], ksize=3, stride=2)
+            # layerN_rn (no bias); its only consumers open with the in-place ReLU -> emit relu(x)
+            pyramid.append(ops.conv(x, P["rn"][i], None, dtype, 256, ksize=3, relu=True))
+
+        F = P["fusion"]
+        # refinenet4: no skip
+        u = self._rcu(F[4]["rcu2"], pyramid[3], dtype)
+        u = ops.conv(u, F[4]["out"][0], F[4]["out"][1], dtype, 256, ksize=1)
+        y = ops.upsample(u, pyramid[2].shape[1], pyramid[2].shape[2], dtype)
+        for lvl, skip, size in ((3, pyramid[2], pyramid[1].shape[1:3]), (2, pyramid[1], pyramid[0].shape[1:3]),
+                                (1, pyramid[0], (2 * pyramid[0].shape[1], 2 * pyramid[0].shape[2]))):
+            xs = self._rcu(F[lvl]["rcu1"], skip, dtype, add2=y, relu_out=True)      # relu(y + RCU1(skip))
+            u = self._rcu(F[lvl]["rcu2"], xs, dtype)
+            u = ops.conv(u, F[lvl]["out"][0], F[lvl]["out"][1], dtype, 256, ksize=1)
+            y = ops.upsample(u, size[0], size[1], dtype)
+        y = ops.conv(y, P["oc1"][0], P["oc1"][1], dtype, 128, ksize=3)
+        y = ops.upsample(y, ph * ps, pw * ps, dtype, pos=self._postab(128, ph * ps, pw * ps, W, H, dev))
+        hmap = ops.conv(y, P["oc2a"][0], P["oc2a"][1], dtype, 32, ksize=3, relu=True, out_f32=True)
+        return ops.dpt_out(hmap, P["oc2b"][0], P["oc2b"][1], head.activation)

@@ -14,7 +14,7 @@ OVG_BF16, OVG_F16, OVG_F32 = 0, 1, 2
 EPI_STORE, EPI_GELU, EPI_RES, EPI_PATCH = 0, 1, 2, 3
 OVG_MAX_SEG = 8
 KV_TILE = 64
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ERRORS = {0: "OVG_OK", -1: "OVG_E_ARG", -2: "OVG_E_DTYPE", -3: "OVG_E_LAUNCH", -4: "OVG_E_UNSUPPORTED"}
 
@@ -96,6 +96,27 @@ class CopyRowsParams(C.Structure):
     _fields_ = [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("n", i64)]
 
 
+class HeadLayerNormParams(C.Structure):
+    _fields_ = [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("weight", vp), ("bias", vp),
+                ("rows", i64), ("p0", i64), ("p1", i64), ("row_off", i64), ("eps", f32), ("dtype", i32)]
+
+
+class ConvParams(C.Structure):
+    _fields_ = [("x", vp), ("ldx", i64), ("w", vp), ("bias", vp), ("y", vp), ("ldy", i64),
+                ("add1", vp), ("ld1", i64), ("add2", vp), ("ld2", i64), ("pos_x", vp), ("pos_y", vp),
+                ("n_img", i64), ("H", i32), ("W", i32), ("Cin", i32), ("Cout", i32), ("w_rows", i32), ("ksize", i32),
+                ("stride", i32), ("upshuffle", i32), ("relu", i32), ("out_f32", i32), ("dtype", i32)]
+
+
+class UpsampleParams(C.Structure):
+    _fields_ = [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("pos_x", vp), ("pos_y", vp),
+                ("n_img", i64), ("H", i32), ("W", i32), ("OH", i32), ("OW", i32), ("C", i32), ("dtype", i32)]
+
+
+class DptOutParams(C.Structure):
+    _fields_ = [("h", vp), ("w2", vp), ("b2", vp), ("val", vp), ("conf", vp), ("npix", i64), ("out_dim", i32), ("activation", i32)]
+
+
 # every entry point of include/omnivggt_hip.h: name -> (restype, argtypes)
 SYMBOLS = {
     "ovg_abi_version": (i32, []),
@@ -112,6 +133,10 @@ SYMBOLS = {
     "ovg_dino_specials": (i32, [C.POINTER(DinoSpecialsParams), vp]),
     "ovg_assemble_tokens": (i32, [C.POINTER(AssembleParams), vp]),
     "ovg_copy_rows": (i32, [C.POINTER(CopyRowsParams), vp]),
+    "ovg_head_layernorm": (i32, [C.POINTER(HeadLayerNormParams), vp]),
+    "ovg_conv": (i32, [C.POINTER(ConvParams), vp]),
+    "ovg_upsample": (i32, [C.POINTER(UpsampleParams), vp]),
+    "ovg_dpt_out": (i32, [C.POINTER(DptOutParams), vp]),
     "ovg_probe_mfma": (i32, [vp, vp, vp, i32, vp]),
     "ovg_debug_set": (i32, [i32, i32]),
 }

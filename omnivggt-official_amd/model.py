@@ -8,14 +8,17 @@
 
 `compute_dtype` selects the aggregator arithmetic: torch.bfloat16 (default, throughput),
 torch.float16, or torch.float32 (parity mode: exact-f32 MFMA, matches the reference CPU
-path to ~1e-5 relative).  Heads always run in f32, like the reference (autocast disabled,
-omnivggt.py:45).
+path to ~1e-5 relative).  The camera head always runs in f32 PyTorch, like the reference (autocast
+disabled, omnivggt.py:45).  The two DPT heads run on the HIP kernels (heads_hip.py, 16-bit NHWC
+implicit-GEMM convolutions) in the 16-bit modes and as f32 PyTorch modules in the parity mode;
+`hip_heads=False` forces the PyTorch heads everywhere.
 """
 import torch
 import torch.nn as nn
 
 from .aggregator import ZeroAggregator
 from .heads import CameraHead, DPTHead
+from .heads_hip import HipDPTHead
 
 try:  # the reference mixes in huggingface_hub.PyTorchModelHubMixin (omnivggt.py:3,10)
     from huggingface_hub import PyTorchModelHubMixin as _HubMixin
@@ -26,8 +29,9 @@ except Exception:  # pragma: no cover - optional
 
 class OmniVGGT(nn.Module, _HubMixin):
     def __init__(self, img_size=518, patch_size=14, embed_dim=1024, depth=24, dino_depth=24,
-                 compute_dtype=torch.bfloat16, dpt_layers=(4, 11, 17, 23)):
+                 compute_dtype=torch.bfloat16, dpt_layers=(4, 11, 17, 23), hip_heads=True):
         super().__init__()
+        self.hip_heads = hip_heads
         self.aggregator = ZeroAggregator(img_size=img_size, patch_size=patch_size, embed_dim=embed_dim, depth=depth,
                                          dino_depth=dino_depth, pose_hidden_dim=9, compute_dtype=compute_dtype)
         layers = tuple(min(l, depth - 1) for l in dpt_layers)
@@ -36,6 +40,15 @@ class OmniVGGT(nn.Module, _HubMixin):
                                   intermediate_layer_idx=layers)
         self.depth_head = DPTHead(dim_in=2 * embed_dim, output_dim=2, activation="exp", conf_activation="expp1",
                                   intermediate_layer_idx=layers)
+        # HIP front ends of the two DPT heads; plain objects (not sub-modules): the parameters and the
+        # state-dict keys stay those of point_head / depth_head
+        self._hip_dpt = {"point": HipDPTHead(self.point_head), "depth": HipDPTHead(self.depth_head)}
+
+    def _dpt(self, which, head, tokens, imgs32, patch_start_idx):
+        dt = self.aggregator.compute_dtype
+        if self.hip_heads and dt in (torch.bfloat16, torch.float16) and imgs32.is_cuda:
+            return self._hip_dpt[which](tokens, imgs32, patch_start_idx, dtype=dt)
+        return head(tokens, images=imgs32, patch_start_idx=patch_start_idx)
 
     def set_compute_dtype(self, dtype):
         self.aggregator.set_compute_dtype(dtype)
@@ -73,9 +86,9 @@ class OmniVGGT(nn.Module, _HubMixin):
                 poses = self.camera_head(cam_tokens)
                 out["pose_enc"], out["pose_enc_list"] = poses[-1], poses
             if self.depth_head is not None:
-                out["depth"], out["depth_conf"] = self.depth_head(tokens, images=imgs32, patch_start_idx=patch_start_idx)
+                out["depth"], out["depth_conf"] = self._dpt("depth", self.depth_head, tokens, imgs32, patch_start_idx)
             if self.point_head is not None:
-                out["world_points"], out["world_points_conf"] = self.point_head(tokens, images=imgs32, patch_start_idx=patch_start_idx)
+                out["world_points"], out["world_points_conf"] = self._dpt("point", self.point_head, tokens, imgs32, patch_start_idx)
             if sharded:
                 for key in ("depth", "depth_conf", "world_points", "world_points_conf"):
                     if key in out:

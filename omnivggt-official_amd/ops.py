@@ -165,3 +165,66 @@ def probe_mfma(a_frag, b_frag, dtype_code):
     rc = L.load().ovg_probe_mfma(L.ptr(a_frag), L.ptr(b_frag), L.ptr(out), dtype_code, _stream())
     L.check(rc, "ovg_probe_mfma")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# DPT head entries (NHWC activations, 16-bit modes)
+# ---------------------------------------------------------------------------------------------
+def head_layernorm(x, weight, bias, eps, dtype, views, tokens_per_view=1374, n_special=5):
+    """x: f32 aggregator output [views*tokens_per_view, 2048] (row stride allowed) -> [views*(tokens_per_view-n_special), 2048]."""
+    _chk_dev(x, weight, bias)
+    p0 = tokens_per_view - n_special
+    out = torch.empty(views * p0, 2048, device=x.device, dtype=dtype)
+    p = L.HeadLayerNormParams(L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), L.ptr(weight), L.ptr(bias),
+                              views * p0, p0, tokens_per_view, n_special, eps, L.dtype_code(dtype))
+    L.call("ovg_head_layernorm", p, _stream())
+    return out
+
+
+def conv(x, w, bias, dtype, cout, ksize=1, stride=1, upshuffle=0, relu=False, add1=None, add2=None, pos=None, out_f32=False):
+    """NHWC convolution. x [n,H,W,Cin] dtype (contiguous), w [w_rows, k*k*Cin] dtype (taps-major), bias f32 [cout] or None.
+    upshuffle = s: ConvTranspose2d(kernel = stride = s) -> [n, H*s, W*s, cout]. pos = (pos_x [OW,cout/2], pos_y [OH,cout/2])."""
+    _chk_dev(x, w, bias, add1, add2)
+    n, H, W, cin = x.shape
+    pad = ksize // 2
+    OH, OW = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+    s = upshuffle if upshuffle > 1 else 1
+    out = torch.empty(n, OH * s, OW * s, cout, device=x.device, dtype=torch.float32 if out_f32 else dtype)
+    p = L.ConvParams()
+    p.x, p.ldx, p.w, p.bias, p.y, p.ldy = L.ptr(x), x.stride(2), L.ptr(w), L.ptr(bias), L.ptr(out), out.stride(2)
+    if add1 is not None:
+        p.add1, p.ld1 = L.ptr(add1), add1.stride(2)
+    if add2 is not None:
+        p.add2, p.ld2 = L.ptr(add2), add2.stride(2)
+    if pos is not None:
+        p.pos_x, p.pos_y = L.ptr(pos[0]), L.ptr(pos[1])
+    p.n_img, p.H, p.W, p.Cin, p.Cout, p.w_rows = n, H, W, cin, cout, w.shape[0]
+    p.ksize, p.stride, p.upshuffle, p.relu, p.out_f32, p.dtype = ksize, stride, upshuffle, 1 if relu else 0, 1 if out_f32 else 0, L.dtype_code(dtype)
+    L.call("ovg_conv", p, _stream())
+    return out
+
+
+def upsample(x, OH, OW, dtype, pos=None):
+    """Bilinear align_corners=True resize of NHWC x [n,H,W,C] -> [n,OH,OW,C] (+ UV position embedding tables)."""
+    _chk_dev(x)
+    n, H, W, c = x.shape
+    out = torch.empty(n, OH, OW, c, device=x.device, dtype=dtype)
+    p = L.UpsampleParams()
+    p.x, p.ldx, p.y, p.ldy = L.ptr(x), x.stride(2), L.ptr(out), out.stride(2)
+    if pos is not None:
+        p.pos_x, p.pos_y = L.ptr(pos[0]), L.ptr(pos[1])
+    p.n_img, p.H, p.W, p.OH, p.OW, p.C, p.dtype = n, H, W, OH, OW, c, L.dtype_code(dtype)
+    L.call("ovg_upsample", p, _stream())
+    return out
+
+
+def dpt_out(h, w2, b2, activation):
+    """h f32 [n,H,W,32] (post-ReLU) -> (val [n,H,W,out_dim-1], conf [n,H,W]); activation 'exp' | 'inv_log'."""
+    _chk_dev(h, w2, b2)
+    n, H, W, _ = h.shape
+    od = w2.shape[0]
+    val = torch.empty(n, H, W, od - 1, device=h.device, dtype=torch.float32)
+    conf = torch.empty(n, H, W, device=h.device, dtype=torch.float32)
+    p = L.DptOutParams(L.ptr(h), L.ptr(w2), L.ptr(b2), L.ptr(val), L.ptr(conf), n * H * W, od, 0 if activation == "exp" else 1)
+    L.call("ovg_dpt_out", p, _stream())
+    return val, conf

@@ -256,6 +256,94 @@ def test_attn(quick):
                 report("attn_%s_%s_rescale_v%d" % (name, cname, variant), out, ref, TOL[name])
 
 
+
+def test_heads(quick):
+    """DPT-head entries (ovg_head_layernorm / ovg_conv / ovg_upsample / ovg_dpt_out) against their torch
+    emulation (tests/head_ops_emul.py) on the same 16-bit inputs, then the whole HipDPTHead against the
+    f32 PyTorch head on CPU."""
+    import head_ops_emul as emul
+    import importlib
+    heads = importlib.import_module("omnivggt_official_amd.heads")
+    heads_hip = importlib.import_module("omnivggt_official_amd.heads_hip")
+    g = torch.Generator().manual_seed(9)
+    for name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        tol = TOL[name]
+        # LayerNorm(2048) with the special-token skip
+        x = rnd(2 * 1374, 2048, g=g) * 2.0 + 0.3
+        w, b = rnd(2048, g=g) * 0.2 + 1.0, rnd(2048, g=g) * 0.1
+        got = ops.head_layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, dt, 2)
+        report("head_layernorm_%s" % name, got, emul.head_layernorm(x, w, b, 1e-5, torch.float32, 2), tol)
+
+        def conv_case(tag, n, H, W, cin, cout, k=1, stride=1, up=0, relu=False, adds=0, pos=False, bias=True, out_f32=False, pad_rows=False):
+            x = (rnd(n, H, W, cin, g=g)).to(dt)
+            rows = (up * up * cout) if up > 1 else cout
+            wt = (rnd(rows, k * k * cin, g=g) * (1.0 / (k * k * cin) ** 0.5)).to(dt)
+            if pad_rows:
+                wp = torch.zeros(128, wt.shape[1], dtype=dt)
+                wp[:rows] = wt
+                wt = wp
+            bs = rnd(cout, g=g) * 0.3 if bias else None
+            pd = k // 2
+            OH, OW = (H + 2 * pd - k) // stride + 1, (W + 2 * pd - k) // stride + 1
+            a1 = rnd(n, OH, OW, cout, g=g).to(dt) if adds >= 1 else None
+            a2 = rnd(n, OH, OW, cout, g=g).to(dt) if adds >= 2 else None
+            ps = (rnd(OW, cout // 2, g=g) * 0.1, rnd(OH, cout // 2, g=g) * 0.1) if pos else None
+            dv = lambda t: None if t is None else t.to(DEV)
+            got = ops.conv(dv(x), dv(wt), dv(bs), dt, cout, ksize=k, stride=stride, upshuffle=up, relu=relu, add1=dv(a1), add2=dv(a2),
+                           pos=None if ps is None else (dv(ps[0]), dv(ps[1])), out_f32=out_f32)
+            ref = emul.conv(x, wt, bs, torch.float32, cout, ksize=k, stride=stride, upshuffle=up, relu=relu, add1=a1, add2=a2, pos=ps, out_f32=True)
+            report("conv_%s_%s" % (tag, name), got, ref, 2e-5 if out_f32 else tol)
+
+        conv_case("1x1_pos_2048to256", 2, 37, 37, 2048, 256, pos=True)
+        conv_case("convT4_256", 1, 37, 37, 256, 256, up=4)
+        conv_case("convT2_512", 1, 37, 37, 512, 512, up=2)
+        conv_case("3x3s2_1024", 1, 37, 37, 1024, 1024, k=3, stride=2)
+        conv_case("3x3_nobias_relu_512to256", 1, 74, 74, 512, 256, k=3, relu=True, bias=False)
+        conv_case("3x3_add2_relu_256", 2, 37, 37, 256, 256, k=3, relu=True, adds=2)
+        conv_case("3x3_add1_256_ragged", 1, 75, 53, 256, 256, k=3, adds=1)
+        conv_case("3x3_256to128", 1, 60, 60, 256, 128, k=3)
+        conv_case("3x3_128to32_f32out", 1, 70, 66, 128, 32, k=3, relu=True, out_f32=True, pad_rows=True)
+        if not quick:
+            conv_case("1x1_256", 1, 148, 148, 256, 256)
+        # bilinear align_corners resize (+ UV tables)
+        for tag, n, H, W, OH, OW, c, pos in (("19to37", 2, 19, 19, 37, 37, 256, False), ("37to74", 1, 37, 37, 74, 74, 256, False),
+                                             ("148to296", 1, 148, 148, 296, 296, 256, False), ("296to518_pos", 1, 296, 296, 518, 518, 128, True)):
+            x = rnd(n, H, W, c, g=g).to(dt)
+            ps = (rnd(OW, c // 2, g=g) * 0.1, rnd(OH, c // 2, g=g) * 0.1) if pos else None
+            got = ops.upsample(x.to(DEV), OH, OW, dt, pos=None if ps is None else (ps[0].to(DEV), ps[1].to(DEV)))
+            report("upsample_%s_%s" % (tag, name), got, emul.upsample(x, OH, OW, torch.float32, pos=ps), tol)
+    for act, od in (("exp", 2), ("inv_log", 4)):
+        h = F.relu(rnd(3, 50, 41, 32, g=g))
+        w2, b2 = rnd(od, 32, g=g) * 0.2, rnd(od, g=g) * 0.1
+        val, conf = ops.dpt_out(h.to(DEV), w2.to(DEV), b2.to(DEV), act)
+        rv, rc = emul.dpt_out(h, w2, b2, act)
+        report("dpt_out_%s_val" % act, val, rv, 2e-5)
+        report("dpt_out_%s_conf" % act, conf, rc, 2e-5)
+    # whole head: HIP (16-bit) vs PyTorch f32 on CPU, S = 2
+    for od, act in ((2, "exp"), (4, "inv_log")):
+        torch.manual_seed(11 + od)
+        head = heads.DPTHead(dim_in=2048, output_dim=od, activation=act, conf_activation="expp1", intermediate_layer_idx=(0, 1, 2, 3)).eval()
+        with torch.no_grad():
+            for pname, prm in head.named_parameters():
+                if prm.dim() > 1:
+                    prm.mul_(1.6)
+                elif "bias" in pname:
+                    prm.uniform_(-0.2, 0.2)
+            last = head.scratch.output_conv2[2]
+            last.weight.mul_(0.2 / float(last.weight.abs().max()))
+            toks = [rnd(1, 2, 1374, 2048, g=g) * 0.7 for _ in range(4)]
+            images = torch.zeros(1, 2, 3, 518, 518)
+            rv, rc = head(toks, images=images, patch_start_idx=5)
+            hip = heads_hip.HipDPTHead(head)
+            toks_d = [t.to(DEV) for t in toks]
+            for name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+                val, conf = hip(toks_d, images.to(DEV), 5, dtype=dt)
+                report("dpt_head_%s_%s_val" % (act, name), val, rv, 4e-2 if name == "bf16" else 6e-3)
+                report("dpt_head_%s_%s_conf" % (act, name), conf, rc, 4e-2 if name == "bf16" else 6e-3)
+            if quick:
+                break
+
+
 def test_embed():
     g = torch.Generator().manual_seed(6)
     V, Hp = 2, 518
@@ -417,7 +505,8 @@ def main():
     L.require_gpu()
     print(L.load().ovg_build_info().decode(), torch.cuda.get_device_name(0), flush=True)
     tests = {"probe": test_probe, "layernorm": test_layernorm, "linear": lambda: test_linear(args.quick), "qkv": lambda: test_qkv(args.quick),
-             "attn": lambda: test_attn(args.quick), "embed": test_embed, "block": lambda: test_block(args.quick)}
+             "attn": lambda: test_attn(args.quick), "embed": test_embed, "block": lambda: test_block(args.quick),
+             "heads": lambda: test_heads(args.quick)}
     for name, fn in tests.items():
         if args.only and name not in args.only.split(","):
             continue

@@ -56,6 +56,11 @@ def test_block_forward():
     _assert_clean()
 
 
+def test_dpt_head_kernels_and_whole_head():
+    st.test_heads(False)
+    _assert_clean()
+
+
 def test_loaded_library_is_the_in_tree_one():
     import os
     assert os.path.samefile(L.LIB_PATH, os.path.join(os.path.dirname(L.__file__), "libomnivggt_hip.so"))
