@@ -26,6 +26,7 @@ from . import ops
 C, HEADS, D = 1024, 16, 64
 RESNET_MEAN = (0.485, 0.456, 0.406)
 RESNET_STD = (0.229, 0.224, 0.225)
+ROPE_MAX_POS = 128      # RoPE table rows: patch coordinates 1..127 -> inputs up to 1778 px per side
 
 
 # ----------------------------------------------------------------------------
@@ -131,7 +132,7 @@ class BlockRunner:
         self.tensors, self.weights = t, w
         if rope:
             if rope_tables is None:
-                rope_tables = make_rope_tables(38, device)
+                rope_tables = make_rope_tables(ROPE_MAX_POS, device)
             self.rope_tables = rope_tables
 
     def params(self, ws, x_in, x_out, inject=None, inj_period=0, tokens_per_view=1374, grid_w=37, n_special=5):
@@ -186,10 +187,10 @@ class ZeroAggregator(nn.Module):
         self.patch_start_idx = 1 + num_register_tokens
         self.aa_block_num = depth
         grid = img_size // patch_size
-        self.grid, self.n_patches = grid, grid * grid
-        self.tokens_per_view = self.n_patches + self.patch_start_idx
+        self.grid = grid                                  # the TRAINED (square) patch grid = pos_embed geometry
+        self.set_geometry(img_size, img_size)             # per-call geometry; forward() resets it from the input
 
-        self.patch_embed = DinoParams(embed_dim, dino_depth, self.n_patches, num_register_tokens)
+        self.patch_embed = DinoParams(embed_dim, dino_depth, grid * grid, num_register_tokens)
         self.frame_blocks = nn.ModuleList([BlockParamsModule(embed_dim, True, 1e-5, init_values) for _ in range(depth)])
         self.global_blocks = nn.ModuleList([BlockParamsModule(embed_dim, True, 1e-5, init_values) for _ in range(depth)])
         self.camera_token = nn.Parameter(torch.randn(1, 2, 1, embed_dim) * 1e-6)
@@ -242,6 +243,38 @@ class ZeroAggregator(nn.Module):
         self._packed = None
         self._ws = {}
 
+    # ------------------------------------------------------------------
+    def set_geometry(self, H, W):
+        """Patch-grid geometry of the current input (any H, W that are multiples of the patch size, like the
+        reference: layers/patch_embed.py:72-73). Non-518x518 inputs get a resampled pos_embed (pos_table)."""
+        ps = self.patch_size
+        if H % ps or W % ps:
+            raise AssertionError(f"Input image height {H} / width {W} is not a multiple of patch size {ps}")
+        gh, gw = H // ps, W // ps
+        if max(gh, gw) + 1 > ROPE_MAX_POS:
+            raise ValueError("inputs larger than %d px per side are not supported" % ((ROPE_MAX_POS - 1) * ps))
+        self.grid_hw = (gh, gw)
+        self.n_patches = gh * gw
+        self.tokens_per_view = self.n_patches + self.patch_start_idx
+        return gh, gw
+
+    def pos_table(self, pk, gh, gw):
+        """f32 [1 + gh*gw, 1024] on the device: the cls position row, then the patch position rows for this
+        grid -- pos_embed itself for the trained square grid, otherwise DINOv2's bicubic + antialias
+        resampling (layers/vision_transformer.py:180-212 with interpolate_offset=0.0, aggregator.py:156-157),
+        evaluated once per geometry with the same ATen CPU op the reference calls, then cached."""
+        if (gh, gw) == (self.grid, self.grid):
+            return pk["pos_embed"]
+        key = ("pos", gh, gw)
+        if key not in pk:
+            pe = self.patch_embed.pos_embed.detach().float().cpu()
+            M = self.grid
+            patch = torch.nn.functional.interpolate(pe[:, 1:].reshape(1, M, M, C).permute(0, 3, 1, 2), mode="bicubic",
+                                                    antialias=True, size=(gh, gw))
+            patch = patch.permute(0, 2, 3, 1).reshape(-1, C)
+            pk[key] = torch.cat((pe[0, :1], patch), dim=0).contiguous().to(pk["device"])
+        return pk[key]
+
     def set_compute_dtype(self, dtype):
         if dtype not in (torch.bfloat16, torch.float16, torch.float32):
             raise ValueError("compute dtype must be bf16, f16 or f32")
@@ -257,7 +290,7 @@ class ZeroAggregator(nn.Module):
         dt = self.compute_dtype
         sd = {k: v for k, v in self.state_dict().items()}
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
-        rope = make_rope_tables(self.grid + 1, device, self.rope_freq)
+        rope = make_rope_tables(ROPE_MAX_POS, device, self.rope_freq)
         pk = {"device": device, "dtype": dt, "rope": rope}
         pk["dino"] = [BlockRunner(sd, "patch_embed.blocks.%d" % i, dt, device, False, False, 1e-6, attn_variant=self.attn_variant)
                       for i in range(self.dino_depth)]
@@ -369,9 +402,10 @@ class ZeroAggregator(nn.Module):
         imgs = images.reshape(K, C_in, H, W)[lo:hi].float().contiguous()
         cols = ops.im2col_rgb(imgs, dt, mean=RESNET_MEAN, std=RESNET_STD)
         xd = torch.empty(Kl * P, C, device=device, dtype=torch.float32)
-        ops.linear(cols, pk["patch_w"], pk["patch_b"], dt, epilogue=L.EPI_PATCH, out=xd, table=pk["pos_embed"],
+        pos = self.pos_table(pk, *self.grid_hw)
+        ops.linear(cols, pk["patch_w"], pk["patch_b"], dt, epilogue=L.EPI_PATCH, out=xd, table=pos,
                    p0=self.n_patches, p1=P, row_off=self.patch_start_idx)
-        ops.dino_specials(xd, Kl, P, pk["cls"], pk["pos_embed"][0], pk["reg"])
+        ops.dino_specials(xd, Kl, P, pk["cls"], pos[0], pk["reg"])
         ws = self.workspace(Kl * P, P, device)
         for blk in pk["dino"]:
             blk.forward(ws, xd, xd)
@@ -387,16 +421,16 @@ class ZeroAggregator(nn.Module):
         B, S, C_in, H, W = images.shape
         if C_in != 3:
             raise ValueError(f"Expected 3 input channels, got {C_in}")
-        if H != self.img_size or W != self.img_size:
-            raise NotImplementedError("the HIP path handles %dx%d inputs (pos-embed interpolation is a 'next' row)" % (self.img_size, self.img_size))
         if not images.is_cuda:
             raise L.OvgError("ZeroAggregator.forward needs HIP device tensors: there is no CPU fallback")
         if self.shard is not None:
             return self.shard.forward(self, images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index)
         device = images.device
         pk = self.pack(device)
+        gh, gw = self.set_geometry(H, W)
         P, K = self.tokens_per_view, B * S
         T = K * P
+        geo = dict(tokens_per_view=P, grid_w=gw)
         with torch.no_grad():
             tokens0, tables = self.embed(pk, images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index)
             ws_f = self.workspace(T, P, device)
@@ -405,7 +439,7 @@ class ZeroAggregator(nn.Module):
             x = tokens0
             for i in range(self.depth):
                 buf = outs[i].view(T, 2 * C)
-                pk["frame"][i].forward(ws_f, x, buf[:, :C], inject=tables[i + 1], inj_period=P)
-                pk["global"][i].forward(ws_g, buf[:, :C], buf[:, C:], events=self.next_attention_events())
+                pk["frame"][i].forward(ws_f, x, buf[:, :C], inject=tables[i + 1], inj_period=P, **geo)
+                pk["global"][i].forward(ws_g, buf[:, :C], buf[:, C:], events=self.next_attention_events(), **geo)
                 x = buf[:, C:]
         return outs, self.patch_start_idx

@@ -62,25 +62,28 @@ class HipExecutor:
         return (torch.empty((world,) + tuple(ws_g.k.shape), device=self.device, dtype=ws_g.k.dtype),
                 torch.empty((world,) + tuple(ws_g.vt.shape), device=self.device, dtype=ws_g.vt.dtype))
 
+    def _geo(self):
+        return dict(tokens_per_view=self.agg.tokens_per_view, grid_w=self.agg.grid_hw[1])
+
     def frame_block(self, i, ws, x_in, x_out, inject, P):
-        self.pk["frame"][i].forward(ws, x_in, x_out, inject=inject, inj_period=P)
+        self.pk["frame"][i].forward(ws, x_in, x_out, inject=inject, inj_period=P, **self._geo())
 
     def global_kv(self, i, ws, x_in, x_out):
         from . import lib as L
-        p = self.pk["global"][i].params(ws, x_in, x_out)
+        p = self.pk["global"][i].params(ws, x_in, x_out, **self._geo())
         p.qkv_part = 1
         L.call("ovg_block_attn_prologue", p, torch.cuda.current_stream().cuda_stream)
         return ws.k, ws.vt
 
     def global_q(self, i, ws, x_in, x_out):
         from . import lib as L
-        p = self.pk["global"][i].params(ws, x_in, x_out)
+        p = self.pk["global"][i].params(ws, x_in, x_out, **self._geo())
         p.qkv_part = 2
         L.call("ovg_block_attn_prologue", p, torch.cuda.current_stream().cuda_stream)
 
     def global_rest(self, i, ws, x_in, x_out, kg, vg, counts, rank):
         from . import lib as L
-        p = self.pk["global"][i].params(ws, x_in, x_out)
+        p = self.pk["global"][i].params(ws, x_in, x_out, **self._geo())
         e = 0
         for r, nk in enumerate(counts):
             if r == rank:
@@ -115,6 +118,7 @@ class ViewSharding:
             raise ValueError("fewer views (%d) than ranks (%d)" % (S, self.world))
         if self.world > ops.L.OVG_MAX_SEG:
             raise ValueError("at most %d ranks per attention call" % ops.L.OVG_MAX_SEG)
+        agg.set_geometry(images.shape[-2], images.shape[-1])
         P = agg.tokens_per_view
         parts = partition(S, self.world)
         self.last_partition = parts

@@ -105,14 +105,32 @@ def patch_conv(x, sd, prefix):
     return y.flatten(2).transpose(1, 2)
 
 
+def interpolate_pos_encoding(pos_embed, npatch, h_px, w_px):
+    """layers/vision_transformer.py:180-212 as the aggregator configures it (aggregator.py:156-157:
+    interpolate_antialias=True, interpolate_offset=0.0 -> `size=` form): identity when the patch grid is the
+    trained square one, else bicubic + antialias resampling of the patch rows to (h_px/14, w_px/14)."""
+    N = pos_embed.shape[1] - 1
+    if npatch == N and h_px == w_px:
+        return pos_embed
+    pe = pos_embed.float()
+    class_pos, patch_pos = pe[:, 0], pe[:, 1:]
+    dim = pe.shape[-1]
+    g0, g1 = h_px // PATCH, w_px // PATCH
+    M = int(math.sqrt(N))
+    assert N == M * M
+    patch_pos = F.interpolate(patch_pos.reshape(1, M, M, dim).permute(0, 3, 1, 2), mode="bicubic", antialias=True, size=(g0, g1))
+    assert (g0, g1) == tuple(patch_pos.shape[-2:])
+    patch_pos = patch_pos.permute(0, 2, 3, 1).reshape(1, -1, dim)
+    return torch.cat((class_pos.unsqueeze(0), patch_pos), dim=1).to(pos_embed.dtype)
+
+
 def dino_backbone(images_norm, sd, prefix="aggregator.patch_embed", depth=24, return_prenorm=False):
-    """layers/vision_transformer.py:214-226,252-271 for square inputs whose patch grid
-    equals the pos_embed grid (interpolate_pos_encoding early-out, :184-185)."""
+    """layers/vision_transformer.py:214-226,252-271."""
+    h_px, w_px = images_norm.shape[-2:]
     x = patch_conv(images_norm, sd, prefix + ".patch_embed")
     V = x.shape[0]
     x = torch.cat((sd[prefix + ".cls_token"].expand(V, -1, -1), x), dim=1)
-    assert x.shape[1] == sd[prefix + ".pos_embed"].shape[1], "oracle supports the no-interpolation case only"
-    x = x + sd[prefix + ".pos_embed"]
+    x = x + interpolate_pos_encoding(sd[prefix + ".pos_embed"], x.shape[1] - 1, h_px, w_px)
     x = torch.cat((x[:, :1], sd[prefix + ".register_tokens"].expand(V, -1, -1), x[:, 1:]), dim=1)
     for i in range(depth):
         x = block(x, sd, "%s.blocks.%d" % (prefix, i), eps=DINO_LN_EPS)
@@ -428,8 +446,10 @@ def model_forward(sd, images, extrinsics, intrinsics, depth, mask, depth_gt_inde
 # synthetic inputs: seeded, identical on every host
 # ----------------------------------------------------------------------------
 def synthetic_inputs(S, seed=1234, hw=518):
+    """hw: int (square) or (H, W)."""
     g = torch.Generator().manual_seed(seed)
-    images = torch.rand(1, S, 3, hw, hw, generator=g)
+    Hh, Ww = (hw, hw) if isinstance(hw, int) else hw
+    images = torch.rand(1, S, 3, Hh, Ww, generator=g)
     q = torch.randn(S, 4, generator=g)
     q = q / q.norm(dim=-1, keepdim=True)
     i, j, k, r = q.unbind(-1)
@@ -443,9 +463,9 @@ def synthetic_inputs(S, seed=1234, hw=518):
     intrinsics = torch.zeros(1, S, 3, 3)
     intrinsics[0, :, 0, 0] = f
     intrinsics[0, :, 1, 1] = f
-    intrinsics[0, :, 0, 2] = hw / 2
-    intrinsics[0, :, 1, 2] = hw / 2
+    intrinsics[0, :, 0, 2] = Ww / 2
+    intrinsics[0, :, 1, 2] = Hh / 2
     intrinsics[0, :, 2, 2] = 1
-    depth = 0.5 + 5 * torch.rand(1, S, hw, hw, 1, generator=g)
-    mask = (torch.rand(1, S, hw, hw, generator=g) > 0.2).float()
+    depth = 0.5 + 5 * torch.rand(1, S, Hh, Ww, 1, generator=g)
+    mask = (torch.rand(1, S, Hh, Ww, generator=g) > 0.2).float()
     return dict(images=images, extrinsics=extrinsics, intrinsics=intrinsics, depth=depth, mask=mask)

@@ -26,13 +26,16 @@ from omnivggt_official_amd import weights  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 CASES = {
-    # name: (S, depth_gt_index, camera_gt_index)
+    # name: (S, depth_gt_index, camera_gt_index[, (H, W)])   -- 518 x 518 unless given
     "s2_images_only": (2, [], []),
     "s3_partial_aux": (3, [1], [0, 2]),
     "s2_full_aux": (2, [0, 1], [0, 1]),
+    # non-square input = the reference's own example geometry (392 x 518 after load_and_preprocess_images):
+    # exercises the bicubic-antialias pos-embed interpolation (vision_transformer.py:180-212) and gh != gw RoPE
+    "s2_392x518_aux": (2, [1], [0, 1], (392, 518)),
 }
 TOK_LAYERS = (0, 4, 11, 17, 23)
-TOK_ROWS = (0, 1, 4, 5, 700, 1373)
+TOK_ROWS = (0, 1, 4, 5, 700, -1)        # -1 = last token of the view (1373 at 518 x 518)
 
 
 def sample_tokens(toks):
@@ -53,9 +56,14 @@ def main():
     model = ref_shim.build_reference_model()
     missing = model.load_state_dict(sd, strict=True)
     print("reference load_state_dict(strict=True):", missing)
-    report = {}
-    for name, (S, dgi, cgi) in CASES.items():
-        inp = orc.synthetic_inputs(S)
+    only = sys.argv[1:]                       # optional: regenerate just these cases, keep the rest of the report
+    rep_path = os.path.join(GOLD, "oracle_vs_reference_report.json")
+    report = json.load(open(rep_path)) if (only and os.path.exists(rep_path)) else {}
+    for name, case in CASES.items():
+        if only and name not in only:
+            continue
+        S, dgi, cgi = case[:3]
+        inp = orc.synthetic_inputs(S, hw=case[3] if len(case) > 3 else 518)
         t0 = time.time()
         with torch.no_grad():
             captured = {}
@@ -87,7 +95,7 @@ def main():
         gold["world_points"] = ref["world_points"][0, :, ::37, ::37].contiguous().numpy()
         gold["world_points_conf"] = ref["world_points_conf"][0, :, ::37, ::37].contiguous().numpy()
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), **gold)
-    json.dump(report, open(os.path.join(GOLD, "oracle_vs_reference_report.json"), "w"), indent=1)
+    json.dump(report, open(rep_path, "w"), indent=1)
     print("done")
 
 

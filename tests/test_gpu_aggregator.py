@@ -37,14 +37,14 @@ def build(sd, depth, dino_depth, dtype):
     return m.to(DEV).eval()
 
 
-def run_agg(m, S, dgi, cgi):
-    inp = common.inputs_for(S, DEV)
+def run_agg(m, S, dgi, cgi, hw=518):
+    inp = common.inputs_for(S, DEV, hw=hw)
     with torch.no_grad():
         return m.aggregator(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
 
 
-def run_full(m, S, dgi, cgi):
-    inp = common.inputs_for(S, DEV)
+def run_full(m, S, dgi, cgi, hw=518):
+    inp = common.inputs_for(S, DEV, hw=hw)
     with torch.no_grad():
         return m(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
 
@@ -70,6 +70,44 @@ def test_f32_parity_all_modality_combos_depth2(reduced, S, dgi, cgi):
         assert common.max_rel(toks[l].cpu(), ref[l]) <= F32_TOL
 
 
+@pytest.mark.parametrize("hw", [(392, 518), (518, 392), (266, 266)])
+def test_f32_parity_other_resolutions_depth2(reduced, hw):
+    """non-square / non-trained grids -- resampled pos_embed (bicubic + antialias), gh != gw RoPE
+    positions, depth patchify and camera FoV on the real (H, W); f32 parity vs the oracle, then the whole dict."""
+    sd, m = reduced
+    S, dgi, cgi = 2, [1], [0, 1]
+    inp = orc.synthetic_inputs(S, hw=hw)
+    with torch.no_grad():
+        ref = orc.model_forward(sd, inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi,
+                                depth_layers=2, dino_layers=2)
+    out = run_full(m, S, dgi, cgi, hw=hw)
+    toks, _ = run_agg(m, S, dgi, cgi, hw=hw)
+    P = (hw[0] // 14) * (hw[1] // 14) + 5
+    for l in range(2):
+        assert toks[l].shape == (1, S, P, 2048)
+        assert common.max_rel(toks[l].cpu(), ref["_tokens"][l]) <= F32_TOL
+    for key in ("pose_enc", "depth", "depth_conf", "world_points", "world_points_conf"):
+        assert out[key].shape == ref[key].shape
+        assert common.max_rel(out[key].cpu(), ref[key]) <= F32_TOL, key
+
+
+def test_low_precision_other_resolution_depth2(reduced):
+    """bf16 aggregator + HIP DPT heads on a 392 x 518 input: finite, right shapes, close to the f32 oracle."""
+    sd, _ = reduced
+    m = build(sd, 2, 2, torch.bfloat16)
+    S, dgi, cgi, hw = 2, [1], [0, 1], (392, 518)
+    inp = orc.synthetic_inputs(S, hw=hw)
+    with torch.no_grad():
+        ref = orc.model_forward(sd, inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi,
+                                depth_layers=2, dino_layers=2)
+    out = run_full(m, S, dgi, cgi, hw=hw)
+    for key in ("depth", "depth_conf", "world_points", "world_points_conf"):
+        assert out[key].shape == ref[key].shape and torch.isfinite(out[key]).all()
+        err = common.max_rel(out[key].cpu(), ref[key])
+        print("bf16 392x518 %s max-rel vs f32 oracle %.2e" % (key, err))
+        assert err <= 0.15, key
+
+
 def test_f32_end_to_end_dict_depth2(reduced):
     """OmniVGGT.forward contract (keys, shapes, values) with the PyTorch heads, vs the oracle."""
     sd, m = reduced
@@ -91,12 +129,13 @@ def full_model():
     return build(common.full_state_dict(), 24, 24, torch.float32)
 
 
-@pytest.mark.parametrize("name", ["s2_images_only", "s3_partial_aux", "s2_full_aux"])
+@pytest.mark.parametrize("name", ["s2_images_only", "s3_partial_aux", "s2_full_aux", "s2_392x518_aux"])
 def test_f32_full_depth_vs_reference_golden(full_model, name):
-    """Full 24+24+24-block aggregator in f32 parity mode against the REAL reference's tokens."""
+    """Full 24+24+24-block aggregator in f32 parity mode against the REAL reference's tokens
+    (the 392 x 518 case goes through the resampled pos_embed and a 28 x 37 RoPE grid: SURVEY 8(f) N2)."""
     full_model.set_compute_dtype(torch.float32)
-    S, dgi, cgi = common.CASES[name]
-    toks, start = run_agg(full_model, S, dgi, cgi)
+    S, dgi, cgi, hw = common.case(name)
+    toks, start = run_agg(full_model, S, dgi, cgi, hw=hw)
     gold = common.load_golden(name)
     worst = 0.0
     for l in common.TOK_LAYERS:
@@ -108,11 +147,12 @@ def test_f32_full_depth_vs_reference_golden(full_model, name):
     print("f32 full-depth %s: worst sampled token max-rel %.2e" % (name, worst))
 
 
-def test_f32_full_depth_predictions_vs_reference_golden(full_model):
+@pytest.mark.parametrize("name", ["s3_partial_aux", "s2_392x518_aux"])
+def test_f32_full_depth_predictions_vs_reference_golden(full_model, name):
     full_model.set_compute_dtype(torch.float32)
-    S, dgi, cgi = common.CASES["s3_partial_aux"]
-    out = run_full(full_model, S, dgi, cgi)
-    gold = common.load_golden("s3_partial_aux")
+    S, dgi, cgi, hw = common.case(name)
+    out = run_full(full_model, S, dgi, cgi, hw=hw)
+    gold = common.load_golden(name)
     assert common.max_rel(out["pose_enc"].cpu(), gold["pose_enc"]) <= F32_TOL
     assert common.max_rel(out["depth"][0, :, ::37, ::37, 0].cpu(), gold["depth"]) <= F32_TOL
     assert common.max_rel(out["depth_conf"][0, :, ::37, ::37].cpu(), gold["depth_conf"]) <= F32_TOL
@@ -122,7 +162,7 @@ def test_f32_full_depth_predictions_vs_reference_golden(full_model):
 @pytest.mark.parametrize("dtype,tok_tol", [(torch.bfloat16, 0.2), (torch.float16, 0.05)])
 def test_low_precision_modes_vs_golden(full_model, dtype, tok_tol):
     full_model.set_compute_dtype(dtype)
-    S, dgi, cgi = common.CASES["s3_partial_aux"]
+    S, dgi, cgi, _ = common.case("s3_partial_aux")
     toks, start = run_agg(full_model, S, dgi, cgi)
     gold = common.load_golden("s3_partial_aux")
     errs = {l: common.max_rel(common.sample_tokens([t.cpu() for t in toks], l), gold["tok_L%d" % l]) for l in common.TOK_LAYERS}
@@ -156,7 +196,7 @@ def test_rejects_bad_inputs():
     m = build(sd, 1, 1, torch.bfloat16)
     with pytest.raises(ValueError):
         m.aggregator(torch.zeros(1, 2, 4, 518, 518, device=DEV), None, None, None, None, [], [])
-    with pytest.raises(NotImplementedError):
-        m.aggregator(torch.zeros(1, 2, 3, 392, 518, device=DEV), None, None, None, None, [], [])
+    with pytest.raises(AssertionError):        # not a multiple of the patch size (reference: patch_embed.py:72-73)
+        m.aggregator(torch.zeros(1, 2, 3, 400, 518, device=DEV), None, None, None, None, [], [])
     with pytest.raises(L.OvgError):
         m.aggregator(torch.zeros(1, 2, 3, 518, 518), None, None, None, None, [], [])

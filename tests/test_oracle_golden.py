@@ -18,11 +18,11 @@ def test_reference_report_says_bit_exact():
         assert max(case["oracle_vs_reference_max_rel"].values()) <= 2e-5
 
 
-@pytest.mark.parametrize("name", ["s2_images_only", "s3_partial_aux", "s2_full_aux"])
+@pytest.mark.parametrize("name", ["s2_images_only", "s3_partial_aux", "s2_full_aux", "s2_392x518_aux"])
 def test_oracle_reproduces_reference_golden(name):
-    S, dgi, cgi = common.CASES[name]
+    S, dgi, cgi, hw = common.case(name)
     sd = common.full_state_dict()
-    inp = orc.synthetic_inputs(S)
+    inp = orc.synthetic_inputs(S, hw=hw)
     torch.set_num_threads(min(32, os.cpu_count()))   # 256-thread intra-op on the GPU box is far slower than 32
     with torch.no_grad():
         out = orc.model_forward(sd, inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)

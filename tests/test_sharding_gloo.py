@@ -100,6 +100,11 @@ class OracleExecutor:
 class FakeAgg:
     depth, tokens_per_view, patch_start_idx = DEPTH, 1374, 5
 
+    def set_geometry(self, H, W):                      # same contract as ZeroAggregator.set_geometry
+        self.grid_hw = (H // 14, W // 14)
+        self.tokens_per_view = self.grid_hw[0] * self.grid_hw[1] + self.patch_start_idx
+        return self.grid_hw
+
 
 def _worker(rank, world, port, S, dgi, cgi, result_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
