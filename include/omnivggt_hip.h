@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-/* 2: + DPT-head entries (ovg_head_layernorm, ovg_conv, ovg_upsample, ovg_dpt_out) */
+/* 2: + DPT-head entries (ovg_head_layernorm, ovg_conv, ovg_upsample, ovg_dpt_out) and ovg_unproject */
 #define OVG_ABI_VERSION 2
 
 enum { OVG_BF16 = 0, OVG_F16 = 1, OVG_F32 = 2 };
@@ -325,6 +325,23 @@ typedef struct {
   int64_t npix; int out_dim; int activation;
 } ovg_dpt_out_params;
 int ovg_dpt_out(const ovg_dpt_out_params*, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Post-processing on the device: depth maps -> world-frame point maps,
+ * utils/geometry.py:151-266 (unproject_depth_map_to_point_map -> depth_to_world_coords_points ->
+ * depth_to_cam_coords_points), which the reference runs as a per-frame numpy loop on the host.
+ *   depth [S, H, W] f32;  cam [S, 16] f32 per frame: cam-to-world rotation row-major (9), cam-to-world
+ *   translation (3), fu, fv, cu, cv (closed_form_inverse_se3 of the extrinsic and the intrinsic entries,
+ *   prepared by the caller);  out [S, H, W, 3] f32.
+ *   x_cam = (u - cu) * d / fu, y_cam = (v - cv) * d / fv evaluated in double and rounded to f32 exactly like
+ *   the numpy expression (int64 pixel grid promotes it to float64), then world = R * cam + t in double (the
+ *   reference's inverse pose is float64) rounded to f32 on store (the reference returns float64).
+ * ------------------------------------------------------------------ */
+typedef struct {
+  const float* depth; const float* cam; float* out;
+  int64_t S; int H; int W;
+} ovg_unproject_params;
+int ovg_unproject(const ovg_unproject_params*, void* stream);
 
 /* MFMA lane-map probe (diagnostics; tools/selftest.py): fills out[64*4] with
  * acc of one 16x16 MFMA for dtype given raw 16-byte A/B fragments per lane. */

@@ -270,6 +270,27 @@ __global__ __launch_bounds__(256) void dpt_out_kernel(ovg_dpt_out_params p) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// depth -> world points (utils/geometry.py:151-266); HBM bound: 4 B read + 12 B written per pixel
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void unproject_kernel(ovg_unproject_params p, int64_t total) {
+  const int64_t hw = (int64_t)p.H * p.W;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t s = idx / hw, rem = idx - s * hw;
+    const int v = (int)(rem / p.W), u = (int)(rem - (int64_t)v * p.W);
+    const float* c = p.cam + s * 16;
+    const float d = p.depth[idx];
+    const float xc = (float)(((double)u - (double)c[14]) * (double)d / (double)c[12]);
+    const float yc = (float)(((double)v - (double)c[15]) * (double)d / (double)c[13]);
+    // the reference's inverse pose is float64 (np.eye), so np.dot(cam_f32, R^T) + t runs in double
+    const double X = xc, Y = yc, Z = d;
+    float* o = p.out + idx * 3;
+    o[0] = (float)((double)c[0] * X + (double)c[1] * Y + (double)c[2] * Z + (double)c[9]);
+    o[1] = (float)((double)c[3] * X + (double)c[4] * Y + (double)c[5] * Z + (double)c[10]);
+    o[2] = (float)((double)c[6] * X + (double)c[7] * Y + (double)c[8] * Z + (double)c[11]);
+  }
+}
+
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 unsigned grid_1d(int64_t work, int per_block, int cap = 1 << 16) {
@@ -347,6 +368,14 @@ extern "C" int ovg_dpt_out(const ovg_dpt_out_params* p, void* stream) {
   if (!p || !p->h || !p->w2 || !p->b2 || !p->val || !p->conf || p->npix <= 0) return OVG_E_ARG;
   if (p->out_dim < 2 || p->out_dim > 4 || (p->activation != 0 && p->activation != 1) || !al16(p->h)) return OVG_E_ARG;
   OVG_LAUNCH(dpt_out_kernel, dim3(grid_1d(p->npix, 256, 1 << 20)), dim3(256), 0, static_cast<hipStream_t>(stream), *p);
+  OVG_CHECK_LAUNCH();
+  return OVG_OK;
+}
+
+extern "C" int ovg_unproject(const ovg_unproject_params* p, void* stream) {
+  if (!p || !p->depth || !p->cam || !p->out || p->S <= 0 || p->H <= 0 || p->W <= 0) return OVG_E_ARG;
+  const int64_t total = p->S * p->H * p->W;
+  OVG_LAUNCH(unproject_kernel, dim3(grid_1d(total, 256, 1 << 20)), dim3(256), 0, static_cast<hipStream_t>(stream), *p, total);
   OVG_CHECK_LAUNCH();
   return OVG_OK;
 }

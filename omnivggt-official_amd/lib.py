@@ -117,6 +117,10 @@ class DptOutParams(C.Structure):
     _fields_ = [("h", vp), ("w2", vp), ("b2", vp), ("val", vp), ("conf", vp), ("npix", i64), ("out_dim", i32), ("activation", i32)]
 
 
+class UnprojectParams(C.Structure):
+    _fields_ = [("depth", vp), ("cam", vp), ("out", vp), ("S", i64), ("H", i32), ("W", i32)]
+
+
 # every entry point of include/omnivggt_hip.h: name -> (restype, argtypes)
 SYMBOLS = {
     "ovg_abi_version": (i32, []),
@@ -137,6 +141,7 @@ SYMBOLS = {
     "ovg_conv": (i32, [C.POINTER(ConvParams), vp]),
     "ovg_upsample": (i32, [C.POINTER(UpsampleParams), vp]),
     "ovg_dpt_out": (i32, [C.POINTER(DptOutParams), vp]),
+    "ovg_unproject": (i32, [C.POINTER(UnprojectParams), vp]),
     "ovg_probe_mfma": (i32, [vp, vp, vp, i32, vp]),
     "ovg_debug_set": (i32, [i32, i32]),
 }

@@ -228,3 +228,13 @@ def dpt_out(h, w2, b2, activation):
     p = L.DptOutParams(L.ptr(h), L.ptr(w2), L.ptr(b2), L.ptr(val), L.ptr(conf), n * H * W, od, 0 if activation == "exp" else 1)
     L.call("ovg_dpt_out", p, _stream())
     return val, conf
+
+
+def unproject(depth, cam):
+    """depth f32 [S,H,W], cam f32 [S,16] (cam-to-world R row-major, t, fu, fv, cu, cv) -> world points [S,H,W,3] f32."""
+    _chk_dev(depth, cam)
+    S, H, W = depth.shape
+    out = torch.empty(S, H, W, 3, device=depth.device, dtype=torch.float32)
+    p = L.UnprojectParams(L.ptr(depth), L.ptr(cam), L.ptr(out), S, H, W)
+    L.call("ovg_unproject", p, _stream())
+    return out
