@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--e2e", action="store_true", help="also time OmniVGGT.forward incl. the PyTorch heads (MIOpen JIT makes the first call slow)")
     ap.add_argument("--attn-variant", type=int, default=0)
     ap.add_argument("--aux", action="store_true", help="depth + camera tokens on every view (BASELINE configs[2] with --views 16)")
+    ap.add_argument("--partial-aux", action="store_true", help="cameras on the even views, depth on the second half of the views "
+                    "(BASELINE configs[4] with --views 128 --dtype f16)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,14 +111,15 @@ def main():
         agg.shard = ViewSharding(gather_output=False)
     def measure(S, steps, warmup):
         """Time `steps` aggregator forwards on S views; returns the result dict (rank-reduced)."""
-        inp = synthetic_inputs(S, dev, aux=args.aux)
+        inp = synthetic_inputs(S, dev, aux=args.aux or args.partial_aux)
         idx = list(range(S)) if args.aux else []
+        didx, cidx = (list(range(S // 2, S)), list(range(0, S, 2))) if args.partial_aux else (idx, idx)
         n_local = S // world + (1 if rank < S % world else 0)
         nq_local, nk_total = n_local * P_TOK, S * P_TOK
         agg.enable_attention_events(steps * agg.depth)   # live HIP-event timing of the global-attention launches
 
         def step():
-            return agg(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], idx, idx)
+            return agg(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], didx, cidx)
 
         def barrier():
             if dist is not None:
@@ -143,11 +146,11 @@ def main():
         launch_flops = 4.0 * nq_local * nk_total * 1024           # one global-attention launch on this rank
         achieved = launch_flops / (attn_avg_ms * 1e-3) / 1e12 if attn_avg_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.dtype]
-        cfg = "2" if (args.aux and S == 16) else ("-" if args.aux else {8: "1", 64: "3"}.get(S, "-"))
+        cfg = "2" if (args.aux and S == 16) else ("4" if (args.partial_aux and S == 128) else ("-" if (args.aux or args.partial_aux) else {8: "1", 64: "3"}.get(S, "-")))
         res = {
             "value": round(S * steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 3),
             "config": {"workload": "OmniVGGT aggregator forward, %d views 518x518 %s (BASELINE configs[%s]), view-sharded over %d GPU(s)"
-                                   % (S, "+ depth + camera tokens" if args.aux else "images-only", cfg, world),
+                                   % (S, "+ depth + camera tokens" if args.aux else ("+ partial aux (cameras on even views, depth on the second half)" if args.partial_aux else "images-only"), cfg, world),
                        "views": S, "views_per_gpu": n_local, "tokens": S * P_TOK, "weights": "seeded synthetic (no checkpoint offline)",
                        "parallelism": "view-shard x%d" % world},
             "algorithmic_tflop_per_step": round(f_total / 1e12, 2),

@@ -535,10 +535,12 @@ template <typename T>
 int dispatch16(const ovg_attn_params& p, hipStream_t st) {
   int v = p.variant;
   // measured best: QB=4 for long sequences, QB=2 for 1374; bf16 takes the speculative anchored-softmax
-  // kernel (exact, see ovg_attn_spec.h), f16 the lazy-rescale attn3 (P would overflow in f16)
+  // kernel (exact, see ovg_attn_spec.h). f16 keeps the lazy-rescale attn3 by default: its speculative build
+  // (variants 21 / 25, anchor 4 log2 units above the first-tile max) only has a 20-unit window before P
+  // saturates, and on the A/B data (logit spread ~45 units) every workgroup pays the fallback: 2x slower
   constexpr bool kBf16 = std::is_same<T, bf16_t>::value;
   if (v == 0) v = kBf16 ? (p.nq >= 4096 ? 21 : 25) : (p.nq >= 4096 ? 6 : 8);
-  if (!kBf16 && v >= 16) return OVG_E_ARG;
+  if (!kBf16 && v >= 16 && v != 18 && v != 19 && v != 21 && v != 25) return OVG_E_ARG;   // f16: production + forced-fallback builds only
   switch (v) {
     case 1: return launch_attn<T, 1, false>(p, st);
     case 2: return launch_attn<T, 2, false>(p, st);
@@ -556,6 +558,14 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
     case 14: return launch_attn3<T, 4, 4, false, 2>(p, st);   // EXPERIMENT (not exact in general): no running max at all
     case 15: return launch_attn3<T, 2, 4, false, 2>(p, st);
     case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28:
+      if constexpr (!kBf16) {
+        switch (v) {
+          case 18: return launch_attn_spec<T, 4, 4, 2, 0, 0, true>(p, st);
+          case 19: return launch_attn_spec<T, 2, 4, 2, 0, 0, true>(p, st);
+          case 21: return launch_attn_spec<T, 4, 4, 1, 0, 0>(p, st);
+          default: return launch_attn_spec<T, 2, 4, 1, 0, 0>(p, st);         // 25
+        }
+      }
       if constexpr (kBf16) {   // speculative anchored softmax + verified fallback: <QB, WAVES, ANCHOR, DMA, HALF>
         switch (v) {
           case 16: return launch_attn_spec<T, 4, 4, 2, 0, 0>(p, st);

@@ -18,7 +18,9 @@
 // result is always the exact softmax; a failed speculation only costs time. A row needs a logit
 // spread of more than ~100 log2 units (e^69) against its anchor to fail.
 //
-// f16 mode keeps attn3 (P would overflow at 2^16).
+// f16: P overflows at 2^16 and loses precision below 2^-14, so its anchor sits ANCHOR_MARGIN = 4 log2 units
+// above the first-tile max (P <= 2^-4 there, 20 units of head-room before the f16 conversion saturates to inf;
+// an inf P makes l inf and triggers the fallback like any other failed speculation).
 //
 // Template knobs (measured against each other with tests/bench_kernels.py):
 //   ANCHOR 0 none (m_ref = 0) | 1 per row | 2 one per lane, shared by the QB rows a lane owns (4
@@ -49,6 +51,8 @@ OVG_DEV u32x4 pack2(const f32x4 a, const f32x4 b) {
 }
 
 template <bool B> struct Tag { static constexpr bool value = B; };
+template <typename T> struct AnchorMargin { static constexpr float value = 0.f; };
+template <> struct AnchorMargin<f16_t> { static constexpr float value = 4.f; };
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -260,7 +264,7 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       const f32x4 sq[4] = {s[0][qb], s[1][qb], s[2][qb], s[3][qb]};
-      mx[qb] = row_max(sq);
+      mx[qb] = row_max(sq) + AnchorMargin<T>::value;
     }
     if constexpr (ANCHOR == 1) {
 #pragma unroll

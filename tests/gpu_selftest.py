@@ -202,6 +202,7 @@ def attn_reference(q, k, v):
     return torch.softmax(s, dim=-1) @ v
 
 
+SPEC_VARIANTS_F16 = (18, 19, 21, 25)       # f16: production + forced-fallback builds of the speculative kernel
 SPEC_VARIANTS = (16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28)   # speculative anchored-softmax kernels (bf16 only)
 
 
@@ -213,6 +214,8 @@ def test_attn(quick):
         variants = (1,) if name == "f32" else (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)   # default, baseline, attn2, attn3 variants
         if name == "bf16":
             variants += SPEC_VARIANTS
+        elif name == "f16":
+            variants += SPEC_VARIANTS_F16
         if quick:
             shapes = shapes[:2]
         for cname, BH, nq, nks in shapes:
@@ -251,7 +254,7 @@ def test_attn(quick):
             qd[:, :nq] = q.to(DEV)
             kd[:, :nk] = k.to(DEV)
             vtd[:, :, :nk] = v.transpose(1, 2).to(DEV)
-            for variant in ((1,) if name == "f32" else (0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13) + (SPEC_VARIANTS if name == "bf16" else ())):
+            for variant in ((1,) if name == "f32" else (0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13) + (SPEC_VARIANTS if name == "bf16" else SPEC_VARIANTS_F16)):
                 out = ops.flash_attn(qd, [(kd, vtd, nk)], nq, dt, variant=variant)
                 report("attn_%s_%s_rescale_v%d" % (name, cname, variant), out, ref, TOL[name])
 
