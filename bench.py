@@ -155,8 +155,8 @@ def main():
                        "parallelism": "view-shard x%d" % world},
             "algorithmic_tflop_per_step": round(f_total / 1e12, 2),
             "tflops_per_gpu": round(f_total / 1e12 / (dt / steps) / world, 1),
-            "roofline": {"bound": "mfma", "kernel": ({"bf16": "attn_spec_kernel<bf16,QB=4,WAVES=4> (speculative anchored softmax + verified fallback)",
-                                                       "f16": "attn3_kernel<f16,QB=4,WAVES=4>"}.get(args.dtype, "attn_kernel<float,1>"))
+            "roofline": {"bound": "mfma", "kernel": ({"bf16": "attn16_kernel<bf16,QB=4,WAVES=4,MODE=0> (speculative anchored softmax + verified fallback)",
+                                                       "f16": "attn16_kernel<f16,QB=4,WAVES=4,MODE=1> (lazy-rescale online softmax)"}.get(args.dtype, "attn_kernel<float,1>"))
                          + " (global cross-view attention, D=64)", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": None, "flop_per_launch": launch_flops,
                          "avg_launch_ms": round(attn_avg_ms, 4), "launches_timed": len(attn_ms)},

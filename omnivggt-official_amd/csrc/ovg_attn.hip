@@ -249,341 +249,55 @@ __global__ __launch_bounds__(256) void attn_kernel(ovg_attn_params p, int nqt, i
   }
 }
 
-// ---------------------------------------------------------------------------
-// Tuned kernel for the 16-bit types (the throughput path).  Same formulation, plus:
-//  * __launch_bounds__(256, 2): <= 256 registers so hipcc selects VGPR-destination MFMAs
-//    (no v_accvgpr_read/write traffic around the softmax and the O rescale);
-//  * S^T accumulators start from C = -m_ref (an MFMA C operand), so the probabilities are
-//    exp2(acc) with NO per-element subtract; the reference max is only moved when a row's
-//    tile max exceeds it by more than RESCALE_THR (lazy rescale, exact: every quantity at
-//    the old reference -- O, l, and the pending S' -- is rescaled together before any exp);
-//  * row max / row sum across the 4 lanes of a q row by v_permlane32_swap/16_swap (no LDS);
-//  * V^T tile stored with the same XOR swizzle as K and its keys permuted inside each
-//    32-key block so a PV fragment is ONE conflict-free ds_read_b128.
-// ---------------------------------------------------------------------------
-constexpr float RESCALE_THR = 8.0f;   // log2 units: p <= 256
+#include "ovg_attn16.h"
 
-// Cross-lane reductions over the 4 lanes {l, l^16, l^32, l^48} of a q row with the gfx950 swap
-// instructions (v_permlane32_swap: upper half of vdst <-> lower half of src; v_permlane16_swap:
-// odd 16-lane rows of vdst <-> even rows of src).  With the same value in both operands the two
-// results hold, per lane, the value and its partner's.
-// NOTE: extract the two results into scalars first -- __builtin_bit_cast applied directly to
-// `r[1]` (a vector-element lvalue) reads element 0 with this hipcc (ROCm 7.2).
-OVG_DEV float swap32_partner_max(float v) {
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  const unsigned a = r[0], b = r[1];
-  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
-}
-OVG_DEV float swap16_partner_max(float v) {
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  const unsigned a = r[0], b = r[1];
-  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
-}
-OVG_DEV float xl_max4(float v) { return swap16_partner_max(swap32_partner_max(v)); }
-OVG_DEV float xl_sum4(float v) {
-  unsigned u = __builtin_bit_cast(unsigned, v);
-  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  unsigned a = r[0], b = r[1];
-  v = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
-  u = __builtin_bit_cast(unsigned, v);
-  r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  a = r[0]; b = r[1];
-  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
-}
-
-template <typename T> OVG_DEV f32x4 mma_c(const u32x4& a, const u32x4& b, const f32x4& c);
-template <> OVG_DEV f32x4 mma_c<bf16_t>(const u32x4& a, const u32x4& b, const f32x4& c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-template <> OVG_DEV f32x4 mma_c<f16_t>(const u32x4& a, const u32x4& b, const f32x4& c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-
+// baseline kernel (all dtypes; the f32 parity path and the in-process reference of the A/B tool)
 template <typename T, int QB>
-__global__ __launch_bounds__(256, 2) void attn2_kernel(ovg_attn_params p, int nqt, int total_tiles) {
-  static_assert(sizeof(T) == 2, "16-bit types only");
-  constexpr int RB = 128, KT_B = BC * RB, VT_B = OVG_D * RB, CPT = 2, BQ = 64 * QB;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (KT_B + VT_B)];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, lr = lane & 15;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = lid / nqt, qt = lid % nqt;
-  const int nq = (int)p.nq;
-  const int q0 = qt * BQ + wave * 16 * QB;
-
-  u32x4 qf[QB][2];
-  {
-    const unsigned char* qbase = static_cast<const unsigned char*>(p.q) + (int64_t)bh * p.nq_pad * RB;
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-      int q = q0 + qb * 16 + lr; q = q < nq ? q : nq - 1;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-        qf[qb][kk] = *reinterpret_cast<const u32x4*>(qbase + (int64_t)q * RB + (4 * kk + g) * 16);
-    }
-  }
-  f32x4 o[QB][4];
-  f32x4 negm[QB];
-  float mref[QB], lrow[QB];
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    mref[qb] = 0.f; lrow[qb] = 0.f; negm[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[qb][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-
-  int fseg = 0, ftile = 0;
-  int f_ntiles = (int)((p.seg[0].nk + BC - 1) / BC);
-  u32x4 rk[CPT], rv[CPT];
-  int k_goff[CPT], v_row[CPT], v_ch[CPT], k_loff[CPT], v_loff0[CPT], v_loff1[CPT];
-#pragma unroll
-  for (int i = 0; i < CPT; ++i) {
-    const int c = tid + 256 * i;
-    const int row = c >> 3, ch = c & 7;
-    k_goff[i] = c * 16;
-    k_loff[i] = swz_off<128>(row, ch);
-    v_row[i] = row; v_ch[i] = ch;
-    // key permutation inside each 32-key block (see header comment): half hf of source chunk
-    // ch lands in chunk 4u + 2(c4&1) + hf, half (c4>>1)
-    const int u = ch >> 2, c4 = ch & 3;
-    v_loff0[i] = swz_off<128>(row, 4 * u + 2 * (c4 & 1) + 0) + 8 * (c4 >> 1);
-    v_loff1[i] = swz_off<128>(row, 4 * u + 2 * (c4 & 1) + 1) + 8 * (c4 >> 1);
-  }
-  auto fetch = [&]() {
-    const ovg_kv_segment sg = p.seg[fseg];
-    const unsigned char* kb = static_cast<const unsigned char*>(sg.k) + ((int64_t)bh * sg.nk_pad + (int64_t)ftile * BC) * RB;
-    const unsigned char* vb = static_cast<const unsigned char*>(sg.vt) + ((int64_t)bh * OVG_D * sg.nk_pad + (int64_t)ftile * BC) * 2;
-#pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      rk[i] = *reinterpret_cast<const u32x4*>(kb + k_goff[i]);
-      rv[i] = *reinterpret_cast<const u32x4*>(vb + (int64_t)v_row[i] * sg.nk_pad * 2 + v_ch[i] * 16);
-    }
-    if (++ftile == f_ntiles) {
-      ftile = 0; ++fseg;
-      if (fseg < p.nseg) f_ntiles = (int)((p.seg[fseg].nk + BC - 1) / BC);
-    }
-  };
-  auto stash = [&](int buf) {
-    unsigned char* kl = lds + buf * (KT_B + VT_B);
-    unsigned char* vl = kl + KT_B;
-#pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      *reinterpret_cast<u32x4*>(kl + k_loff[i]) = rk[i];
-      *reinterpret_cast<u32x2*>(vl + v_loff0[i]) = u32x2{rv[i][0], rv[i][1]};
-      *reinterpret_cast<u32x2*>(vl + v_loff1[i]) = u32x2{rv[i][2], rv[i][3]};
-    }
-  };
-
-  int cseg = 0, ctile = 0;
-  int c_ntiles = f_ntiles;
-  int c_nk = (int)p.seg[0].nk;
-  const int sx = lr >> 1;                           // swizzle term of this lane's LDS rows
-
-  fetch();
-  stash(0);
-  __syncthreads();
-
-  int buf = 0;
-  for (int j = 0; j < total_tiles; ++j) {
-    const bool more = (j + 1) < total_tiles;
-    if (more) fetch();
-    const unsigned char* kl = lds + buf * (KT_B + VT_B);
-    const unsigned char* vl = kl + KT_B;
-
-    // ---- S' = K Q^T - m_ref ----------------------------------------------
-    f32x4 s[QB][4];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const u32x4 k0 = *reinterpret_cast<const u32x4*>(kl + (16 * kt + lr) * 128 + (((0 + g) ^ sx) << 4));
-      const u32x4 k1 = *reinterpret_cast<const u32x4*>(kl + (16 * kt + lr) * 128 + (((4 + g) ^ sx) << 4));
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        s[qb][kt] = mma_c<T>(k0, qf[qb][0], negm[qb]);
-        s[qb][kt] = mma_c<T>(k1, qf[qb][1], s[qb][kt]);
-      }
-    }
-    const int kv0 = ctile * BC;
-    if (kv0 + BC > c_nk) {
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool dead = (kv0 + 16 * kt + 4 * g + r) >= c_nk;
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb) s[qb][kt][r] = dead ? -INFINITY : s[qb][kt][r];
-        }
-    }
-    // ---- lazy-rescale online softmax --------------------------------------
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-      float mx = fmaxf(fmaxf(s[qb][0][0], s[qb][0][1]), fmaxf(s[qb][0][2], s[qb][0][3]));
-#pragma unroll
-      for (int kt = 1; kt < 4; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(s[qb][kt][0], s[qb][kt][1]), fmaxf(s[qb][kt][2], s[qb][kt][3])));
-      mx = xl_max4(mx);
-      if (j == 0) {
-        // first tile: anchor the reference at the true row max (o = l = 0, nothing to rescale)
-        mref[qb] = mx;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) s[qb][kt] -= mx;
-        negm[qb] = f32x4{-mx, -mx, -mx, -mx};
-      } else if (__any(mx > RESCALE_THR)) {
-        const float delta = fmaxf(mx, 0.f);
-        const float alpha = __builtin_amdgcn_exp2f(-delta);
-        mref[qb] += delta;
-        const float nm = -mref[qb];
-        negm[qb] = f32x4{nm, nm, nm, nm};
-        lrow[qb] *= alpha;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) s[qb][kt] -= delta;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[qb][dt] *= alpha;
-      }
-      float rs = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(s[qb][kt][r]);
-          s[qb][kt][r] = pv;
-          rs += pv;
-        }
-      lrow[qb] += rs;
-    }
-    // ---- O^T += V^T P^T ----------------------------------------------------
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      u32x4 pf[QB];
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) pf[qb] = VFrag<T>::pfrag(s[qb], u);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const u32x4 vf = *reinterpret_cast<const u32x4*>(vl + (16 * dt + lr) * 128 + (((4 * u + g) ^ sx) << 4));
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) o[qb][dt] = mma_c<T>(vf, pf[qb], o[qb][dt]);
-      }
-    }
-    if (++ctile == c_ntiles) {
-      ctile = 0; ++cseg;
-      if (cseg < p.nseg) { c_nk = (int)p.seg[cseg].nk; c_ntiles = (c_nk + BC - 1) / BC; }
-    }
-    if (more) stash(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
-  }
-
-  const int bq = bh / OVG_H, hh = bh % OVG_H;
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    const float inv = 1.0f / xl_sum4(lrow[qb]);
-    const int q = q0 + qb * 16 + lr;
-    if (q < nq) {
-      T* dst = static_cast<T*>(p.out) + ((int64_t)bq * nq + q) * p.ldo + hh * OVG_D + 4 * g;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        store4<T>(dst + 16 * dt, o[qb][dt][0] * inv, o[qb][dt][1] * inv, o[qb][dt][2] * inv, o[qb][dt][3] * inv);
-    }
-  }
-}
-
-template <typename T, int QB, bool TUNED>
 int launch_attn(const ovg_attn_params& p, hipStream_t st) {
   constexpr int BQ = 64 * QB;
   const int nqt = (int)((p.nq + BQ - 1) / BQ);
   int total = 0;
   for (int i = 0; i < p.nseg; ++i) total += (int)((p.seg[i].nk + BC - 1) / BC);
   const dim3 grid((unsigned)(p.BH * nqt)), block(256);
-  if constexpr (TUNED) OVG_LAUNCH((attn2_kernel<T, QB>), grid, block, 0, st, p, nqt, total);
-  else OVG_LAUNCH((attn_kernel<T, QB>), grid, block, 0, st, p, nqt, total);
+  OVG_LAUNCH((attn_kernel<T, QB>), grid, block, 0, st, p, nqt, total);
   OVG_CHECK_LAUNCH();
   return OVG_OK;
 }
 
-#include "ovg_attn_v3.h"
-
-template <typename T, int QB, int WAVES, bool PRIO = false, int SM = 0>
-int launch_attn3(const ovg_attn_params& p, hipStream_t st) {
+template <typename T, int QB, int WAVES, int MODE>
+int launch_attn16(const ovg_attn_params& p, hipStream_t st) {
   constexpr int BQ = 16 * QB * WAVES;
   const int nqt = (int)((p.nq + BQ - 1) / BQ);
   int total = 0;
   for (int i = 0; i < p.nseg; ++i) total += (int)((p.seg[i].nk + BC - 1) / BC);
   const dim3 grid((unsigned)(p.BH * nqt)), block(64 * WAVES);
-  OVG_LAUNCH((attn3_kernel<T, QB, WAVES, PRIO, SM>), grid, block, 0, st, p, nqt, total);
+  OVG_LAUNCH((attn16_kernel<T, QB, WAVES, MODE>), grid, block, 0, st, p, nqt, total);
   OVG_CHECK_LAUNCH();
   return OVG_OK;
 }
 
-#include "ovg_attn_spec.h"
-
-template <typename T, int QB, int WAVES, int ANCHOR, int DMA, int HALF, bool FORCE = false>
-int launch_attn_spec(const ovg_attn_params& p, hipStream_t st) {
-  constexpr int BQ = 16 * QB * WAVES;
-  const int nqt = (int)((p.nq + BQ - 1) / BQ);
-  int total = 0;
-  for (int i = 0; i < p.nseg; ++i) total += (int)((p.seg[i].nk + BC - 1) / BC);
-  const dim3 grid((unsigned)(p.BH * nqt)), block(64 * WAVES);
-  OVG_LAUNCH((attn_spec_kernel<T, QB, WAVES, ANCHOR, DMA, HALF, FORCE>), grid, block, 0, st, p, nqt, total);
-  OVG_CHECK_LAUNCH();
-  return OVG_OK;
-}
-
-// variant: 0 = default choice; 1/2 = baseline kernel QB=1/2; 3/4/5 = attn2 QB=2/4/3;
-// 6..10 = attn3 (QB,WAVES) = (4,4) (4,2) (2,4) (2,2) (3,4)
+// variant (benchmark / test knob; numbers kept from the A/B logs under profiles/):
+//   0 = default: bf16 -> speculative kernel (QB = 4), f16 -> lazy-rescale kernel (QB = 4 for nq >= 4096, else 2)
+//   1 / 2   baseline kernel, QB = 1 / 2
+//   6 / 8   attn16 lazy-rescale only (MODE 1), QB = 4 / 2
+//   21 / 25 attn16 speculative + verified fallback (MODE 0), QB = 4 / 2
+//   18 / 19 attn16 with the fallback forced (MODE 2, tests), QB = 4 / 2
 template <typename T>
 int dispatch16(const ovg_attn_params& p, hipStream_t st) {
-  int v = p.variant;
-  // measured best: QB=4 for long sequences, QB=2 for 1374; bf16 takes the speculative anchored-softmax
-  // kernel (exact, see ovg_attn_spec.h). f16 keeps the lazy-rescale attn3 by default: its speculative build
-  // (variants 21 / 25, anchor 4 log2 units above the first-tile max) only has a 20-unit window before P
-  // saturates, and on the A/B data (logit spread ~45 units) every workgroup pays the fallback: 2x slower
   constexpr bool kBf16 = std::is_same<T, bf16_t>::value;
-  if (v == 0) v = kBf16 ? (p.nq >= 4096 ? 21 : 25) : (p.nq >= 4096 ? 6 : 8);
-  if (!kBf16 && v >= 16 && v != 18 && v != 19 && v != 21 && v != 25) return OVG_E_ARG;   // f16: production + forced-fallback builds only
+  int v = p.variant;
+  // measured (profiles/r01_attention_attn16_ab.txt): the speculative kernel is best at QB = 4 for both the global
+  // (nq = S * 1374) and the frame (nq = 1374) shapes; the lazy kernel prefers QB = 2 on the short one
+  if (v == 0) v = kBf16 ? 21 : (p.nq >= 4096 ? 6 : 8);
   switch (v) {
-    case 1: return launch_attn<T, 1, false>(p, st);
-    case 2: return launch_attn<T, 2, false>(p, st);
-    case 3: return launch_attn<T, 2, true>(p, st);
-    case 4: return launch_attn<T, 4, true>(p, st);
-    case 5: return launch_attn<T, 3, true>(p, st);
-    case 6: return launch_attn3<T, 4, 4>(p, st);
-    case 7: return launch_attn3<T, 4, 2>(p, st);
-    case 8: return launch_attn3<T, 2, 4>(p, st);
-    case 9: return launch_attn3<T, 2, 2>(p, st);
-    case 10: return launch_attn3<T, 3, 4>(p, st);
-    case 11: return launch_attn3<T, 4, 4, true>(p, st);   // + s_setprio around the MFMA clusters
-    case 12: return launch_attn3<T, 4, 4, false, 1>(p, st);   // single rescale branch for all q blocks
-    case 13: return launch_attn3<T, 2, 4, false, 1>(p, st);
-    case 14: return launch_attn3<T, 4, 4, false, 2>(p, st);   // EXPERIMENT (not exact in general): no running max at all
-    case 15: return launch_attn3<T, 2, 4, false, 2>(p, st);
-    case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28:
-      if constexpr (!kBf16) {
-        switch (v) {
-          case 18: return launch_attn_spec<T, 4, 4, 2, 0, 0, true>(p, st);
-          case 19: return launch_attn_spec<T, 2, 4, 2, 0, 0, true>(p, st);
-          case 21: return launch_attn_spec<T, 4, 4, 1, 0, 0>(p, st);
-          default: return launch_attn_spec<T, 2, 4, 1, 0, 0>(p, st);         // 25
-        }
-      }
-      if constexpr (kBf16) {   // speculative anchored softmax + verified fallback: <QB, WAVES, ANCHOR, DMA, HALF>
-        switch (v) {
-          case 16: return launch_attn_spec<T, 4, 4, 2, 0, 0>(p, st);
-          case 17: return launch_attn_spec<T, 2, 4, 2, 0, 0>(p, st);
-          case 18: return launch_attn_spec<T, 4, 4, 2, 0, 0, true>(p, st);   // tests: force the fallback recompute
-          case 19: return launch_attn_spec<T, 2, 4, 2, 0, 0, true>(p, st);
-          case 20: return launch_attn_spec<T, 4, 4, 0, 0, 0>(p, st);
-          case 21: return launch_attn_spec<T, 4, 4, 1, 0, 0>(p, st);
-          case 22: return launch_attn_spec<T, 4, 4, 2, 0, 1>(p, st);
-          case 23: return launch_attn_spec<T, 4, 4, 2, 1, 0>(p, st);
-          case 24: return launch_attn_spec<T, 4, 4, 2, 1, 1>(p, st);
-          case 25: return launch_attn_spec<T, 2, 4, 1, 0, 0>(p, st);
-          case 26: return launch_attn_spec<T, 2, 4, 2, 1, 1>(p, st);
-          case 27: return launch_attn_spec<T, 3, 4, 1, 0, 0>(p, st);
-          default: return launch_attn_spec<T, 4, 4, 1, 0, 1>(p, st);
-        }
-      }
-      return OVG_E_ARG;
+    case 1: return launch_attn<T, 1>(p, st);
+    case 2: return launch_attn<T, 2>(p, st);
+    case 6: return launch_attn16<T, 4, 4, 1>(p, st);
+    case 8: return launch_attn16<T, 2, 4, 1>(p, st);
+    case 21: return launch_attn16<T, 4, 4, 0>(p, st);
+    case 25: return launch_attn16<T, 2, 4, 0>(p, st);
+    case 18: return launch_attn16<T, 4, 4, 2>(p, st);
+    case 19: return launch_attn16<T, 2, 4, 2>(p, st);
     default: return OVG_E_ARG;
   }
 }
@@ -605,7 +319,7 @@ extern "C" int ovg_flash_attn(const ovg_attn_params* p, void* stream) {
   switch (p->dtype) {
     case OVG_BF16: return dispatch16<bf16_t>(*p, st);
     case OVG_F16: return dispatch16<f16_t>(*p, st);
-    case OVG_F32: return launch_attn<float, 1, false>(*p, st);
+    case OVG_F32: return launch_attn<float, 1>(*p, st);
     default: return OVG_E_DTYPE;
   }
 }

@@ -1,0 +1,351 @@
+// The tuned 16-bit flash-attention kernel (included by ovg_attn.hip): `attn16_kernel<T, QB, WAVES, MODE>`.
+//
+// Structure (kept from the measured iterations, see profiles/README.md):
+//  * "swapped" MFMA formulation (ovg_attn.hip header): S'^T = K Q^T with -m_ref in the MFMA C operand, so
+//    P = exp2(acc) needs no per-element subtract; P never leaves registers (the V^T LDS tile stores its keys
+//    permuted inside each 32-key block so that a PV fragment is one conflict-free ds_read_b128);
+//  * the row sums come out of the MATRIX pipe: one extra MFMA per (q block, 32-key step) with an all-ones A
+//    operand accumulates sum_k P (PMC on the previous kernel: VALU-active 52 % vs MFMA-busy 33 %);
+//  * __launch_bounds__(NT, 2): <= 256 VGPRs, VGPR-destination MFMAs (no v_accvgpr traffic); the file is
+//    compiled with -fno-honor-nans (no canonicalising v_max before fmaxf of MFMA results);
+//  * K / V^T tiles (64 keys) register-staged into double-buffered LDS: global loads of tile j+1 are issued
+//    before the MFMAs of tile j and written to the other buffer after them; one barrier per tile.
+//
+// Two softmax bodies share that structure (run_tiles<..., SM>):
+//  SM = 0  lazy-rescale online softmax: m_ref moves only when a row's tile max exceeds it by more than
+//          RESCALE_THR = 8 log2 units; O, l and the pending S' are rescaled together before any exp (exact).
+//  SM = 2  speculative ANCHORED softmax. The running max only exists to keep exp2() in range; with bf16 P
+//          (f32 exponent range) and f32 accumulators, O = (sum P v) / (sum P) is invariant to m_ref. The pass
+//          anchors m_ref per row at the max over the FIRST key tile (a prologue outside the loop) and then runs
+//          a branch-free tile body: QK^T (anchor in C) -> v_exp_f32 -> pack -> row-sum MFMA + PV. No max, no
+//          cross-lane traffic, no rescale: ~50 of the 184 VALU instructions per tile and the serial
+//          QK^T -> max -> exp dependency are gone (+10...16 % measured).
+//
+// MODE 0 (bf16 default): run SM = 2, then every row checks on raw bits that l is within 2^+-100 and O is
+//   finite -- exactly the condition that no exp2 overflowed and the row did not flush to zero (l >= max P).
+//   If ANY row of the workgroup fails (__syncthreads_or), the whole workgroup recomputes with SM = 0, so the
+//   result is always the exact softmax; a failed speculation only costs time (a row needs a logit spread of
+//   more than ~100 log2 units = e^69 against its first tile; tests force it with spike / ramp inputs).
+// MODE 1 (f16 default): SM = 0 only. f16 P saturates at 2^16: the f16 speculative build (anchor 4 log2 units
+//   above the first-tile max, 20 units of head-room) pays the fallback on wide-spread logits (2x slower on the
+//   A/B data), so it is available (MODE 0 on f16) but not the default.
+// MODE 2 (tests): MODE 0 with the fallback forced.
+//
+// Measured dead ends, removed from the tree (logs under profiles/): LDS-DMA staging with natural-order V^T
+// (-2 %), 32-key half bodies (-1.5 %), one shared anchor per lane (-1 %), QB = 3 (-5 %), a single merged
+// rescale branch (-1 %), s_setprio around the MFMA clusters (+-0), 2-wave workgroups (-40 %), and intra-wave
+// software pipelining of exp against MFMA (compiler-scheduled, sched_barrier-pinned and sched_group_barrier
+// 1:2:1 forms: -15...-90 %).
+// hipcc trap: hoisting the (rare) tail-mask branch out of the tile body makes it one basic block; the
+// scheduler then interleaves everything, runs out of registers and reloads Q fragments from scratch every
+// tile -- and that reload's s_waitcnt vmcnt(0) drains the K/V prefetch (896 instead of 1154 TFLOP/s). The
+// branch stays between the QK^T cluster and the exponentials on purpose.
+#pragma once
+
+namespace attn16 {
+
+constexpr float RESCALE_THR = 8.0f;            // log2 units: p <= 256
+constexpr uint32_t EXP_HI = 127 + 100, EXP_LO = 127 - 100;
+
+OVG_DEV bool bad_sum(float l) {
+  const uint32_t e = (__builtin_bit_cast(uint32_t, l) >> 23) & 0xffu;
+  return e > EXP_HI || e < EXP_LO;
+}
+OVG_DEV bool nonfinite(float x) { return ((__builtin_bit_cast(uint32_t, x) >> 23) & 0xffu) == 0xffu; }
+
+template <typename T> struct OnesFrag;
+template <> struct OnesFrag<bf16_t> { static OVG_DEV u32x4 get() { return u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}; } };
+template <> struct OnesFrag<f16_t> { static OVG_DEV u32x4 get() { return u32x4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u}; } };
+template <typename T> struct AnchorMargin { static constexpr float value = 0.f; };
+template <> struct AnchorMargin<f16_t> { static constexpr float value = 4.f; };
+
+template <typename T> OVG_DEV f32x4 mma_c(const u32x4& a, const u32x4& b, const f32x4& c);
+template <> OVG_DEV f32x4 mma_c<bf16_t>(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <> OVG_DEV f32x4 mma_c<f16_t>(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// Max over the 4 lanes {l, l^16, l^32, l^48} of a q row with the gfx950 swap instructions
+// (v_permlane32_swap: upper half of vdst <-> lower half of src; v_permlane16_swap: odd 16-lane rows of vdst
+// <-> even rows of src). With the same value in both operands the two results hold the value and its partner's.
+// NOTE: extract the two results into scalars first -- __builtin_bit_cast applied directly to `r[1]` (a
+// vector-element lvalue) reads element 0 with this hipcc (ROCm 7.2).
+OVG_DEV float swap32_partner_max(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const unsigned a = r[0], b = r[1];
+  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+OVG_DEV float swap16_partner_max(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned a = r[0], b = r[1];
+  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+OVG_DEV float xl_max4(float v) { return swap16_partner_max(swap32_partner_max(v)); }
+
+template <typename T>
+OVG_DEV u32x4 pack2(const f32x4 a, const f32x4 b) {
+  T v[8];
+  v[0] = TT<T>::from_f32(a[0]); v[1] = TT<T>::from_f32(a[1]); v[2] = TT<T>::from_f32(a[2]); v[3] = TT<T>::from_f32(a[3]);
+  v[4] = TT<T>::from_f32(b[0]); v[5] = TT<T>::from_f32(b[1]); v[6] = TT<T>::from_f32(b[2]); v[7] = TT<T>::from_f32(b[3]);
+  u32x4 r;
+  __builtin_memcpy(&r, v, 16);
+  return r;
+}
+
+// One pass over all key tiles of all segments for the wave's QB x 16 query rows; leaves the un-normalised
+// O^T in o and the row sums in lacc (every register of lacc[qb] holds the full sum of row q0 + 16 qb + lane&15).
+template <typename T, int QB, int WAVES, int SM>
+OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int bh, const int q0, const int total_tiles,
+                       f32x4 (&o)[QB][4], f32x4 (&lacc)[QB]) {
+  constexpr int NT = 64 * WAVES;
+  constexpr int RB = 128, KT_B = BC * RB, VT_B = OVG_D * RB, CPT = 512 / NT;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int g = lane >> 4, lr = lane & 15;
+  const int nq = (int)p.nq;
+
+  u32x4 qf[QB][2];
+  {
+    const unsigned char* qbase = static_cast<const unsigned char*>(p.q) + (int64_t)bh * p.nq_pad * RB;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      int q = q0 + qb * 16 + lr; q = q < nq ? q : nq - 1;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        qf[qb][kk] = *reinterpret_cast<const u32x4*>(qbase + (int64_t)q * RB + (4 * kk + g) * 16);
+    }
+  }
+  f32x4 negm[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    negm[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    lacc[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[qb][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const u32x4 ones = OnesFrag<T>::get();
+
+  // ---- staging: per-thread chunk coordinates; tile pointers advance incrementally -----------------
+  u32x4 rk[CPT], rv[CPT];
+  int k_goff[CPT], v_row[CPT], v_coff[CPT], k_loff[CPT], v_loff0[CPT], v_loff1[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = tid + NT * i;
+    const int row = c >> 3, ch = c & 7;
+    k_goff[i] = c * 16;
+    k_loff[i] = swz_off<128>(row, ch);
+    v_row[i] = row; v_coff[i] = ch * 16;
+    const int u = ch >> 2, c4 = ch & 3;            // key permutation inside each 32-key block
+    v_loff0[i] = swz_off<128>(row, 4 * u + 2 * (c4 & 1) + 0) + 8 * (c4 >> 1);
+    v_loff1[i] = swz_off<128>(row, 4 * u + 2 * (c4 & 1) + 1) + 8 * (c4 >> 1);
+  }
+  int fseg = 0, ftile = 0;
+  int f_ntiles = (int)((p.seg[0].nk + BC - 1) / BC);
+  const unsigned char* kptr = static_cast<const unsigned char*>(p.seg[0].k) + (int64_t)bh * p.seg[0].nk_pad * RB;
+  const unsigned char* vptr = static_cast<const unsigned char*>(p.seg[0].vt) + (int64_t)bh * OVG_D * p.seg[0].nk_pad * 2;
+  int64_t vstride = p.seg[0].nk_pad * 2;          // bytes between V^T rows (d)
+  auto fetch = [&]() {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      rk[i] = *reinterpret_cast<const u32x4*>(kptr + k_goff[i]);
+      rv[i] = *reinterpret_cast<const u32x4*>(vptr + v_row[i] * vstride + v_coff[i]);
+    }
+    kptr += KT_B;
+    vptr += BC * 2;
+    if (++ftile == f_ntiles) {
+      ftile = 0; ++fseg;
+      if (fseg < p.nseg) {
+        const ovg_kv_segment sg = p.seg[fseg];
+        f_ntiles = (int)((sg.nk + BC - 1) / BC);
+        kptr = static_cast<const unsigned char*>(sg.k) + (int64_t)bh * sg.nk_pad * RB;
+        vptr = static_cast<const unsigned char*>(sg.vt) + (int64_t)bh * OVG_D * sg.nk_pad * 2;
+        vstride = sg.nk_pad * 2;
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+    unsigned char* kl = lds + buf * (KT_B + VT_B);
+    unsigned char* vl = kl + KT_B;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      *reinterpret_cast<u32x4*>(kl + k_loff[i]) = rk[i];
+      *reinterpret_cast<u32x2*>(vl + v_loff0[i]) = u32x2{rv[i][0], rv[i][1]};
+      *reinterpret_cast<u32x2*>(vl + v_loff1[i]) = u32x2{rv[i][2], rv[i][3]};
+    }
+  };
+
+  int cseg = 0, ctile = 0;
+  int c_ntiles = f_ntiles;
+  int c_nk = (int)p.seg[0].nk;
+  const int sx = lr >> 1;
+  const int frag_row = lr * 128;
+  const int coff0 = ((0 + g) ^ sx) << 4, coff1 = ((4 + g) ^ sx) << 4;
+
+  fetch();
+  stash(0);
+  __syncthreads();
+
+  // S'^T blocks s[kt][qb] (keys 16 kt .. 16 kt + 15) of the tile in LDS at kl, dead keys masked to -inf
+  auto qk_tile = [&](const unsigned char* kl, f32x4 (&s)[4][QB], bool tail, int kv0) {
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const u32x4 k0 = *reinterpret_cast<const u32x4*>(kl + kt * 2048 + frag_row + coff0);
+      const u32x4 k1 = *reinterpret_cast<const u32x4*>(kl + kt * 2048 + frag_row + coff1);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        s[kt][qb] = mma_c<T>(k0, qf[qb][0], negm[qb]);
+        s[kt][qb] = mma_c<T>(k1, qf[qb][1], s[kt][qb]);
+      }
+    }
+    if (tail) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool dead = (kv0 + 16 * kt + 4 * g + r) >= c_nk;
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) s[kt][qb][r] = dead ? -INFINITY : s[kt][qb][r];
+        }
+    }
+  };
+  auto row_max = [&](const f32x4 (&s)[4][QB], int qb) {
+    float mx = fmaxf(s[0][qb][0], s[0][qb][1]);
+    mx = fmaxf(fmaxf(mx, s[0][qb][2]), s[0][qb][3]);
+#pragma unroll
+    for (int kt = 1; kt < 4; ++kt) {
+      mx = fmaxf(fmaxf(mx, s[kt][qb][0]), s[kt][qb][1]);
+      mx = fmaxf(fmaxf(mx, s[kt][qb][2]), s[kt][qb][3]);
+    }
+    return xl_max4(mx);
+  };
+  auto exp_qb = [&](f32x4 (&s)[4][QB], int qb) {
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[kt][qb][r] = __builtin_amdgcn_exp2f(s[kt][qb][r]);
+  };
+  // O^T += V^T P^T ; l += 1^T P^T for the 32-key step u (keys 32u + 16 (j>>2) + 4g + (j&3) in slot j)
+  auto pv_step = [&](const unsigned char* vl, int u, const f32x4 (&sa)[QB], const f32x4 (&sb)[QB]) {
+    u32x4 pf[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      pf[qb] = pack2<T>(sa[qb], sb[qb]);
+      lacc[qb] = mma_c<T>(ones, pf[qb], lacc[qb]);
+    }
+    const int voff = ((4 * u + g) ^ sx) << 4;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const u32x4 vf = *reinterpret_cast<const u32x4*>(vl + dt * 2048 + frag_row + voff);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) o[qb][dt] = mma_c<T>(vf, pf[qb], o[qb][dt]);
+    }
+  };
+
+  if constexpr (SM == 2) {
+    // anchor: m_ref = row max over the first key tile (tile 0 is in LDS buffer 0 now)
+    f32x4 s[4][QB];
+    qk_tile(lds, s, BC > c_nk, 0);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const float mx = row_max(s, qb) + AnchorMargin<T>::value;
+      negm[qb] = f32x4{-mx, -mx, -mx, -mx};
+    }
+  }
+
+  int buf = 0;
+  for (int j = 0; j < total_tiles; ++j) {
+    const bool more = (j + 1) < total_tiles;
+    if (more) fetch();
+    const unsigned char* kl = lds + buf * (KT_B + VT_B);
+    const unsigned char* vl = kl + KT_B;
+    const int kv0 = ctile * BC;
+
+    f32x4 s[4][QB];
+    qk_tile(kl, s, kv0 + BC > c_nk, kv0);          // the tail branch doubles as the scheduling fence (header)
+    if constexpr (SM == 2) {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) exp_qb(s, qb);
+    } else {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        const float mx = row_max(s, qb);
+        if (j == 0) {
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) s[kt][qb] -= mx;
+          negm[qb] = f32x4{-mx, -mx, -mx, -mx};
+        } else if (__any(mx > RESCALE_THR)) {
+          const float delta = fmaxf(mx, 0.f);
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          negm[qb] -= delta;
+          lacc[qb] *= alpha;
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) s[kt][qb] -= delta;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) o[qb][dt] *= alpha;
+        }
+        exp_qb(s, qb);
+      }
+    }
+    pv_step(vl, 0, s[0], s[1]);
+    pv_step(vl, 1, s[2], s[3]);
+
+    if (++ctile == c_ntiles) {
+      ctile = 0; ++cseg;
+      if (cseg < p.nseg) { c_nk = (int)p.seg[cseg].nk; c_ntiles = (c_nk + BC - 1) / BC; }
+    }
+    if (more) stash(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+}  // namespace attn16
+
+// MODE: 0 = speculative anchored softmax + verified fallback, 1 = lazy-rescale only, 2 = forced fallback (tests)
+template <typename T, int QB, int WAVES, int MODE>
+__global__ __launch_bounds__(64 * WAVES, 2) void attn16_kernel(ovg_attn_params p, int nqt, int total_tiles) {
+  static_assert(sizeof(T) == 2, "16-bit types only");
+  constexpr int RB = 128, KT_B = BC * RB, VT_B = OVG_D * RB, BQ = 16 * QB * WAVES;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (KT_B + VT_B)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, lr = lane & 15;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = lid / nqt, qt = lid % nqt;
+  const int nq = (int)p.nq;
+  const int q0 = qt * BQ + wave * 16 * QB;
+
+  f32x4 o[QB][4], lacc[QB];
+  if constexpr (MODE == 1) {
+    attn16::run_tiles<T, QB, WAVES, 0>(p, lds, bh, q0, total_tiles, o, lacc);
+  } else {
+    attn16::run_tiles<T, QB, WAVES, 2>(p, lds, bh, q0, total_tiles, o, lacc);
+    bool bad = MODE == 2;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      bad = bad || attn16::bad_sum(lacc[qb][0]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bad = bad || attn16::nonfinite(o[qb][dt][r]);
+    }
+    if (__syncthreads_or(bad ? 1 : 0)) attn16::run_tiles<T, QB, WAVES, 0>(p, lds, bh, q0, total_tiles, o, lacc);
+  }
+
+  const int bq = bh / OVG_H, hh = bh % OVG_H;
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const float inv = 1.0f / lacc[qb][0];        // every row of the ones-MFMA holds the full row sum
+    const int q = q0 + qb * 16 + lr;
+    if (q < nq) {
+      T* dst = static_cast<T*>(p.out) + ((int64_t)bq * nq + q) * p.ldo + hh * OVG_D + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        store4<T>(dst + 16 * dt, o[qb][dt][0] * inv, o[qb][dt][1] * inv, o[qb][dt][2] * inv, o[qb][dt][3] * inv);
+    }
+  }
+}

@@ -202,8 +202,7 @@ def attn_reference(q, k, v):
     return torch.softmax(s, dim=-1) @ v
 
 
-SPEC_VARIANTS_F16 = (18, 19, 21, 25)       # f16: production + forced-fallback builds of the speculative kernel
-SPEC_VARIANTS = (16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28)   # speculative anchored-softmax kernels (bf16 only)
+ATTN16_VARIANTS = (0, 1, 2, 6, 8, 21, 25, 18, 19)   # default, baseline QB1/2, lazy QB4/2, speculative QB4/2, forced fallback QB4/2
 
 
 def test_attn(quick):
@@ -211,11 +210,7 @@ def test_attn(quick):
     for name, dt in DT.items():
         shapes = [("n1374_bh32", 32, 1374, [1374]), ("n2748_2seg", 16, 2748 // 2, [1374, 1374]),
                   ("n700_ragged_seg", 16, 700, [100, 333, 64]), ("n300_seg", 16, 300, [130, 70])]
-        variants = (1,) if name == "f32" else (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)   # default, baseline, attn2, attn3 variants
-        if name == "bf16":
-            variants += SPEC_VARIANTS
-        elif name == "f16":
-            variants += SPEC_VARIANTS_F16
+        variants = (1,) if name == "f32" else ATTN16_VARIANTS
         if quick:
             shapes = shapes[:2]
         for cname, BH, nq, nks in shapes:
@@ -254,7 +249,7 @@ def test_attn(quick):
             qd[:, :nq] = q.to(DEV)
             kd[:, :nk] = k.to(DEV)
             vtd[:, :, :nk] = v.transpose(1, 2).to(DEV)
-            for variant in ((1,) if name == "f32" else (0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13) + (SPEC_VARIANTS if name == "bf16" else SPEC_VARIANTS_F16)):
+            for variant in ((1,) if name == "f32" else ATTN16_VARIANTS):
                 out = ops.flash_attn(qd, [(kd, vtd, nk)], nq, dt, variant=variant)
                 report("attn_%s_%s_rescale_v%d" % (name, cname, variant), out, ref, TOL[name])
 
@@ -467,7 +462,7 @@ def microbench():
             print("gemm %-10s S=%d M=%d N=%d K=%d: %.3f ms  %.1f TFLOP/s" % (nm, S, M, N, K, ms, tf), flush=True)
             out["gemm_%s_S%d" % (nm, S)] = {"ms": ms, "tflops": tf}
         # global attention
-        for variant in (1, 2, 3, 4, 5):
+        for variant in (1, 6, 8, 21, 25):
             BH, n = 16, M
             q, k, vt = ops.alloc_qkv(BH, n, n, dt, DEV)
             q[:, :n] = rnd(BH, n, 64, g=g).to(dt).to(DEV)
@@ -479,7 +474,7 @@ def microbench():
             print("global attn S=%d N=%d variant(QB)=%d: %.3f ms  %.1f TFLOP/s (%.1f%% of 2.5 PF)" % (S, n, variant, ms, tf, tf / 25.0), flush=True)
             out["gattn_S%d_qb%d" % (S, variant)] = {"ms": ms, "tflops": tf}
         # frame attention
-        for variant in (1, 2, 3, 4, 5):
+        for variant in (1, 6, 8, 21, 25):
             BH, n = S * 16, 1374
             q, k, vt = ops.alloc_qkv(BH, n, n, dt, DEV)
             q[:, :n] = rnd(BH, n, 64, g=g).to(dt).to(DEV)

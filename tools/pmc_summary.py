@@ -12,7 +12,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("attn2_kernel", "attn_kernel", "qkv_kernel", "linear_kernel", "layernorm_kernel", "im2col", "assemble", "dino_specials"):
+    for key in ("attn16_kernel", "attn_kernel", "qkv_kernel", "linear_kernel", "layernorm_kernel", "im2col", "assemble", "dino_specials"):
         if key in name:
             i = name.find(key)
             return name[i:i + 60]
