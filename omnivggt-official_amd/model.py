@@ -54,6 +54,18 @@ class OmniVGGT(nn.Module, _HubMixin):
         self.aggregator.set_compute_dtype(dtype)
         return self
 
+    @classmethod
+    def from_safetensors(cls, path, device="cuda", **kwargs):
+        """Construct without running any initialiser (meta device -> to_empty) and load a checkpoint with the
+        reference's key set, e.g. checkpoints/OmniVGGT.safetensors (inference.py:321-325; SURVEY 8(f) N4: the
+        reference spends ~25 s in trunc_normal_ init plus a torch.hub call before it loads the same file)."""
+        from safetensors.torch import load_file
+        with torch.device("meta"):
+            model = cls(**kwargs)
+        model = model.to_empty(device="cpu")
+        model.load_state_dict(load_file(path), strict=True)
+        return model.to(device).eval()
+
     def forward(self, images, extrinsics=None, intrinsics=None, depth=None, mask=None, depth_gt_index=None,
                 camera_gt_index=None):
         if images.dim() == 4:

@@ -140,3 +140,24 @@ def test_heads_match_oracle_on_cpu():
         rp, rpc = orc.dpt_head_forward(sd, "point_head", toks, images, 5, activation="inv_log")
         assert torch.allclose(p, rp, rtol=1e-4, atol=1e-6) and torch.allclose(pc, rpc, rtol=1e-4, atol=1e-6)
         assert d.shape == (1, S, 518, 518, 1) and pc.shape == (1, S, 518, 518)
+
+
+def test_from_safetensors_roundtrip(tmp_path):
+    """checkpoint path -- a safetensors file with the reference's key set loads strictly into a
+    model that was never initialised (meta -> to_empty), and every tensor comes back bit-identical."""
+    import json
+    import os
+    import torch
+    from safetensors.torch import save_file
+    from omnivggt_official_amd import weights
+    from omnivggt_official_amd.model import OmniVGGT
+    here = os.path.dirname(os.path.abspath(__file__))
+    manifest = json.load(open(os.path.join(here, "golden", "state_dict_manifest.json")))
+    sd = weights.synthetic_state_dict(weights.reduce_manifest(manifest, 1, 1), seed=7)
+    path = str(tmp_path / "tiny.safetensors")
+    save_file({k: v.contiguous() for k, v in sd.items()}, path)
+    m = OmniVGGT.from_safetensors(path, device="cpu", depth=1, dino_depth=1)
+    got = m.state_dict()
+    assert set(got) == set(sd)
+    assert all(torch.equal(got[k], sd[k]) for k in sd)
+    assert not m.training
