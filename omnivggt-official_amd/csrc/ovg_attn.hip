@@ -250,7 +250,6 @@ __global__ __launch_bounds__(256) void attn_kernel(ovg_attn_params p, int nqt, i
 }
 
 #include "ovg_attn16.h"
-#include "ovg_attn16pp.h"
 
 // baseline kernel (all dtypes; the f32 parity path and the in-process reference of the A/B tool)
 template <typename T, int QB>
@@ -265,26 +264,14 @@ int launch_attn(const ovg_attn_params& p, hipStream_t st) {
   return OVG_OK;
 }
 
-template <typename T, int QB, int WAVES, int MODE, bool PRIO = false>
+template <typename T, int QB, int WAVES, int MODE>
 int launch_attn16(const ovg_attn_params& p, hipStream_t st) {
   constexpr int BQ = 16 * QB * WAVES;
   const int nqt = (int)((p.nq + BQ - 1) / BQ);
   int total = 0;
   for (int i = 0; i < p.nseg; ++i) total += (int)((p.seg[i].nk + BC - 1) / BC);
   const dim3 grid((unsigned)(p.BH * nqt)), block(64 * WAVES);
-  OVG_LAUNCH((attn16_kernel<T, QB, WAVES, MODE, PRIO>), grid, block, 0, st, p, nqt, total);
-  OVG_CHECK_LAUNCH();
-  return OVG_OK;
-}
-
-template <typename T, bool FORCE>
-int launch_attn16pp(const ovg_attn_params& p, hipStream_t st) {
-  constexpr int BQ = 512;
-  const int nqt = (int)((p.nq + BQ - 1) / BQ);
-  int total = 0;
-  for (int i = 0; i < p.nseg; ++i) total += (int)((p.seg[i].nk + BC - 1) / BC);
-  const dim3 grid((unsigned)(p.BH * nqt)), block(512);
-  OVG_LAUNCH((attn16pp_kernel<T, FORCE>), grid, block, 0, st, p, nqt, total);
+  OVG_LAUNCH((attn16_kernel<T, QB, WAVES, MODE>), grid, block, 0, st, p, nqt, total);
   OVG_CHECK_LAUNCH();
   return OVG_OK;
 }
@@ -311,12 +298,6 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
     case 25: return launch_attn16<T, 2, 4, 0>(p, st);
     case 18: return launch_attn16<T, 4, 4, 2>(p, st);
     case 19: return launch_attn16<T, 2, 4, 2>(p, st);
-    case 41: return launch_attn16<T, 4, 4, 0, true>(p, st);   // speculative, VALU section at s_setprio 2
-    case 45: return launch_attn16<T, 2, 4, 0, true>(p, st);
-    case 46: return launch_attn16<T, 4, 4, 1, true>(p, st);   // lazy, VALU section at s_setprio 2
-    case 48: return launch_attn16<T, 2, 4, 1, true>(p, st);
-    case 31: return launch_attn16pp<T, false>(p, st);   // 8-wave ping-pong form of the speculative kernel
-    case 32: return launch_attn16pp<T, true>(p, st);    // ... with the fallback forced (tests)
     default: return OVG_E_ARG;
   }
 }

@@ -33,9 +33,10 @@
 //
 // Measured dead ends, removed from the tree (logs under profiles/): LDS-DMA staging with natural-order V^T
 // (-2 %), 32-key half bodies (-1.5 %), one shared anchor per lane (-1 %), QB = 3 (-5 %), a single merged
-// rescale branch (-1 %), s_setprio around the MFMA clusters (+-0), 2-wave workgroups (-40 %), and intra-wave
-// software pipelining of exp against MFMA (compiler-scheduled, sched_barrier-pinned and sched_group_barrier
-// 1:2:1 forms: -15...-90 %).
+// rescale branch (-1 %), s_setprio around the MFMA clusters (+-0) or around the exp2/convert section (-4 %),
+// 2-wave workgroups (-40 %), an 8-wave ping-pong with the two waves of a SIMD forced into MFMA / VALU antiphase
+// by barriers (+-0 at S = 64, -17 % at S = 8; profiles/r01_probe_coexec.txt), and intra-wave software pipelining
+// of exp against MFMA (compiler-scheduled, sched_barrier-pinned and sched_group_barrier 1:2:1 forms: -15...-90 %).
 // hipcc trap: hoisting the (rare) tail-mask branch out of the tile body makes it one basic block; the
 // scheduler then interleaves everything, runs out of registers and reloads Q fragments from scratch every
 // tile -- and that reload's s_waitcnt vmcnt(0) drains the K/V prefetch (896 instead of 1154 TFLOP/s). The
@@ -98,7 +99,7 @@ OVG_DEV u32x4 pack2(const f32x4 a, const f32x4 b) {
 
 // One pass over all key tiles of all segments for the wave's QB x 16 query rows; leaves the un-normalised
 // O^T in o and the row sums in lacc (every register of lacc[qb] holds the full sum of row q0 + 16 qb + lane&15).
-template <typename T, int QB, int WAVES, int SM, bool PRIO = false>
+template <typename T, int QB, int WAVES, int SM>
 OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int bh, const int q0, const int total_tiles,
                        f32x4 (&o)[QB][4], f32x4 (&lacc)[QB]) {
   constexpr int NT = 64 * WAVES;
@@ -229,17 +230,6 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
       for (int r = 0; r < 4; ++r) s[kt][qb][r] = __builtin_amdgcn_exp2f(s[kt][qb][r]);
   };
   // O^T += V^T P^T ; l += 1^T P^T for the 32-key step u (keys 32u + 16 (j>>2) + 4g + (j&3) in slot j)
-  auto pv_mma = [&](const unsigned char* vl, int u, const u32x4 (&pf)[QB]) {
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) lacc[qb] = mma_c<T>(ones, pf[qb], lacc[qb]);
-    const int voff = ((4 * u + g) ^ sx) << 4;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const u32x4 vf = *reinterpret_cast<const u32x4*>(vl + dt * 2048 + frag_row + voff);
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) o[qb][dt] = mma_c<T>(vf, pf[qb], o[qb][dt]);
-    }
-  };
   auto pv_step = [&](const unsigned char* vl, int u, const f32x4 (&sa)[QB], const f32x4 (&sb)[QB]) {
     u32x4 pf[QB];
 #pragma unroll
@@ -277,22 +267,7 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
 
     f32x4 s[4][QB];
     qk_tile(kl, s, kv0 + BC > c_nk, kv0);          // the tail branch doubles as the scheduling fence (header)
-    // PRIO: this wave's VALU section (exp2 / convert) takes issue priority over the other wave of the SIMD.
-    // tools/probes/coexec.hip: a VALU stream overlaps fully with another wave's MFMA stream ONLY when the VALU
-    // wave wins the arbitration (older, or higher s_setprio); with the MFMA wave in front the two serialise.
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(2);
-    if constexpr (SM == 2 && PRIO) {
-      u32x4 pf[2][QB];
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) exp_qb(s, qb);
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) pf[u][qb] = pack2<T>(s[2 * u][qb], s[2 * u + 1][qb]);
-      __builtin_amdgcn_s_setprio(0);
-      pv_mma(vl, 0, pf[0]);
-      pv_mma(vl, 1, pf[1]);
-    } else if constexpr (SM == 2) {
+    if constexpr (SM == 2) {
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) exp_qb(s, qb);
     } else {
@@ -316,11 +291,8 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
         exp_qb(s, qb);
       }
     }
-    if constexpr (!(SM == 2 && PRIO)) {
-      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-      pv_step(vl, 0, s[0], s[1]);
-      pv_step(vl, 1, s[2], s[3]);
-    }
+    pv_step(vl, 0, s[0], s[1]);
+    pv_step(vl, 1, s[2], s[3]);
 
     if (++ctile == c_ntiles) {
       ctile = 0; ++cseg;
@@ -335,7 +307,7 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
 }  // namespace attn16
 
 // MODE: 0 = speculative anchored softmax + verified fallback, 1 = lazy-rescale only, 2 = forced fallback (tests)
-template <typename T, int QB, int WAVES, int MODE, bool PRIO = false>
+template <typename T, int QB, int WAVES, int MODE>
 __global__ __launch_bounds__(64 * WAVES, 2) void attn16_kernel(ovg_attn_params p, int nqt, int total_tiles) {
   static_assert(sizeof(T) == 2, "16-bit types only");
   constexpr int RB = 128, KT_B = BC * RB, VT_B = OVG_D * RB, BQ = 16 * QB * WAVES;
@@ -350,9 +322,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn16_kernel(ovg_attn_params p
 
   f32x4 o[QB][4], lacc[QB];
   if constexpr (MODE == 1) {
-    attn16::run_tiles<T, QB, WAVES, 0, PRIO>(p, lds, bh, q0, total_tiles, o, lacc);
+    attn16::run_tiles<T, QB, WAVES, 0>(p, lds, bh, q0, total_tiles, o, lacc);
   } else {
-    attn16::run_tiles<T, QB, WAVES, 2, PRIO>(p, lds, bh, q0, total_tiles, o, lacc);
+    attn16::run_tiles<T, QB, WAVES, 2>(p, lds, bh, q0, total_tiles, o, lacc);
     bool bad = MODE == 2;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
