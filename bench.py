@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=list(DT))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--torch-heads", action="store_true", help="with --e2e: run the DPT heads as f32 PyTorch modules instead of the HIP kernels")
+    ap.add_argument("--e2e-views", type=int, default=8, help="view count of the --e2e measurement")
     ap.add_argument("--e2e", action="store_true", help="also time OmniVGGT.forward incl. the PyTorch heads (MIOpen JIT makes the first call slow)")
     ap.add_argument("--attn-variant", type=int, default=0)
     ap.add_argument("--aux", action="store_true", help="depth + camera tokens on every view (BASELINE configs[2] with --views 16)")
@@ -190,7 +191,7 @@ def main():
             # whole OmniVGGT.forward (aggregator + camera head + the two DPT heads) on the 8-view config; in the
             # 16-bit modes the DPT heads run on the HIP kernels (heads_hip.py), `--torch-heads` forces PyTorch's
             try:
-                Se = 8
+                Se = args.e2e_views
                 inp = synthetic_inputs(Se, dev, aux=args.aux)
                 idx = list(range(Se)) if args.aux else []
                 model.hip_heads = not args.torch_heads
