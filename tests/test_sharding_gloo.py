@@ -106,14 +106,14 @@ class FakeAgg:
         return self.grid_hw
 
 
-def _worker(rank, world, port, S, dgi, cgi, result_dir):
+def _worker(rank, world, port, S, dgi, cgi, result_dir, hw=518):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 2) // world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         sd = common.reduced_state_dict(DEPTH, DINO)
-        inp = orc.synthetic_inputs(S)
+        inp = orc.synthetic_inputs(S, hw=hw)
         sh = sharding.ViewSharding(executor_factory=lambda agg, dev: OracleExecutor(sd, DEPTH), gather_output=True)
         outs, start = sh.forward(FakeAgg(), inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
         assert start == 5 and sh.last_partition == sharding.partition(S, world)
@@ -129,17 +129,19 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("S,dgi,cgi", [(3, [1], [0, 2])])
-def test_view_sharded_forward_matches_monolithic_oracle(tmp_path, S, dgi, cgi):
+@pytest.mark.parametrize("S,dgi,cgi,hw", [(3, [1], [0, 2], 518), (3, [0], [1], (266, 350))])
+def test_view_sharded_forward_matches_monolithic_oracle(tmp_path, S, dgi, cgi, hw):
+    """uneven 2-rank split of 3 views; the second case is a non-square, non-trained patch grid (19 x 25)."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), S, dgi, cgi, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), S, dgi, cgi, str(tmp_path), hw), nprocs=world, join=True)
     sharded = torch.load(os.path.join(str(tmp_path), "sharded.pt"))
     sd = common.reduced_state_dict(DEPTH, DINO)
-    inp = orc.synthetic_inputs(S)
+    inp = orc.synthetic_inputs(S, hw=hw)
+    P = 1374 if hw == 518 else (hw[0] // 14) * (hw[1] // 14) + 5
     with torch.no_grad():
         ref, _ = orc.aggregator_forward(sd, inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi,
                                         depth_layers=DEPTH, dino_layers=DINO)
     assert len(sharded) == DEPTH
     for a, b in zip(sharded, ref):
-        assert a.shape == b.shape == (1, S, 1374, 2048)
+        assert a.shape == b.shape == (1, S, P, 2048)
         assert common.max_rel(a, b) < 2e-5
