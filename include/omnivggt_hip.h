@@ -30,8 +30,9 @@
 extern "C" {
 #endif
 
-/* 2: + DPT-head entries (ovg_head_layernorm, ovg_conv, ovg_upsample, ovg_dpt_out) and ovg_unproject */
-#define OVG_ABI_VERSION 2
+/* 2: + DPT-head entries (ovg_head_layernorm, ovg_conv, ovg_upsample, ovg_dpt_out) and ovg_unproject
+ * 3: + head-parallel sharding (ovg_attn_params.kv_heads / out_bh_stride, ovg_block_params.skip_attention, ovg_heads_to_tokens) */
+#define OVG_ABI_VERSION 3
 
 enum { OVG_BF16 = 0, OVG_F16 = 1, OVG_F32 = 2 };
 
@@ -141,6 +142,12 @@ typedef struct {
   void* out; int64_t ldo;
   int64_t BH; int dtype;
   int variant;   /* 0 = default; >0 selects tuning variants */
+  /* head-parallel (all-to-all) sharding, both 0 otherwise:
+   *   kv_heads > 0: K / V^T segments hold kv_heads heads; batch entry bh reads head bh % kv_heads (the BH entries
+   *                 are (source rank, head) pairs of queries that share this rank's heads);
+   *   out_bh_stride > 0: head-major output, out + bh * out_bh_stride + q * ldo + d (ldo >= 64) instead of the
+   *                 token-major row (bh / 16) * nq + q, column (bh % 16) * 64 + d. */
+  int kv_heads; int64_t out_bh_stride;
 } ovg_attn_params;
 int ovg_flash_attn(const ovg_attn_params*, void* stream);
 
@@ -189,6 +196,7 @@ typedef struct {
   /* optional hipEvent_t handles recorded on `stream` immediately before / after the
    * flash-attention launch (bench.py: live per-kernel timing); NULL = not recorded */
   void* ev_attn_start; void* ev_attn_stop;
+  int skip_attention;  /* ovg_block_attn_epilogue only: ws_attn already holds the attention output (head-parallel sharding) */
 } ovg_block_params;
 /* whole block */
 int ovg_block_forward(const ovg_block_params*, void* stream);
@@ -342,6 +350,13 @@ typedef struct {
   int64_t S; int H; int W;
 } ovg_unproject_params;
 int ovg_unproject(const ovg_unproject_params*, void* stream);
+
+/* head-major -> token-major: x [heads, n_pad, 64] dtype -> y [n, heads*64] dtype (row stride ldy), the layout the
+ * proj GEMM reads; used after the return all-to-all of the head-parallel sharded attention. */
+typedef struct {
+  const void* x; int64_t n_pad; void* y; int64_t ldy; int64_t n; int heads; int dtype;
+} ovg_heads_to_tokens_params;
+int ovg_heads_to_tokens(const ovg_heads_to_tokens_params*, void* stream);
 
 /* MFMA lane-map probe (diagnostics; tools/selftest.py): fills out[64*4] with
  * acc of one 16x16 MFMA for dtype given raw 16-byte A/B fragments per lane. */

@@ -113,8 +113,9 @@ __global__ __launch_bounds__(256) void attn_kernel(ovg_attn_params p, int nqt, i
   }
   auto fetch = [&]() {
     const ovg_kv_segment sg = p.seg[fseg];
-    const unsigned char* kb = static_cast<const unsigned char*>(sg.k) + ((int64_t)bh * sg.nk_pad + (int64_t)ftile * BC) * RB;
-    const unsigned char* vb = static_cast<const unsigned char*>(sg.vt) + ((int64_t)bh * OVG_D * sg.nk_pad + (int64_t)ftile * BC) * (int64_t)sizeof(T);
+    const int kvh = p.kv_heads > 0 ? bh % p.kv_heads : bh;
+    const unsigned char* kb = static_cast<const unsigned char*>(sg.k) + ((int64_t)kvh * sg.nk_pad + (int64_t)ftile * BC) * RB;
+    const unsigned char* vb = static_cast<const unsigned char*>(sg.vt) + ((int64_t)kvh * OVG_D * sg.nk_pad + (int64_t)ftile * BC) * (int64_t)sizeof(T);
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       rk[i] = *reinterpret_cast<const u32x4*>(kb + k_goff[i]);
@@ -241,7 +242,8 @@ __global__ __launch_bounds__(256) void attn_kernel(ovg_attn_params p, int nqt, i
     const float inv = 1.0f / lt;
     const int q = q0 + qb * 16 + lr;
     if (q < nq) {
-      T* dst = static_cast<T*>(p.out) + ((int64_t)bq * nq + q) * p.ldo + hh * OVG_D + 4 * g;
+      T* dst = p.out_bh_stride > 0 ? static_cast<T*>(p.out) + (int64_t)bh * p.out_bh_stride + (int64_t)q * p.ldo + 4 * g
+                                   : static_cast<T*>(p.out) + ((int64_t)bq * nq + q) * p.ldo + hh * OVG_D + 4 * g;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
         store4<T>(dst + 16 * dt, o[qb][dt][0] * inv, o[qb][dt][1] * inv, o[qb][dt][2] * inv, o[qb][dt][3] * inv);
@@ -314,7 +316,7 @@ extern "C" int ovg_flash_attn(const ovg_attn_params* p, void* stream) {
     if ((reinterpret_cast<uintptr_t>(s.k) | reinterpret_cast<uintptr_t>(s.vt)) & 15) return OVG_E_ARG;
   }
   if ((reinterpret_cast<uintptr_t>(p->q) | reinterpret_cast<uintptr_t>(p->out)) & 15) return OVG_E_ARG;
-  if (p->ldo % 4) return OVG_E_ARG;
+  if (p->ldo % 4 || p->kv_heads < 0 || p->out_bh_stride < 0 || (p->out_bh_stride > 0 && (p->ldo < OVG_D || p->out_bh_stride % 4))) return OVG_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (p->dtype) {
     case OVG_BF16: return dispatch16<bf16_t>(*p, st);

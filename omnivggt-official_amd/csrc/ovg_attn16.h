@@ -146,8 +146,9 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
   }
   int fseg = 0, ftile = 0;
   int f_ntiles = (int)((p.seg[0].nk + BC - 1) / BC);
-  const unsigned char* kptr = static_cast<const unsigned char*>(p.seg[0].k) + (int64_t)bh * p.seg[0].nk_pad * RB;
-  const unsigned char* vptr = static_cast<const unsigned char*>(p.seg[0].vt) + (int64_t)bh * OVG_D * p.seg[0].nk_pad * 2;
+  const int kvh = p.kv_heads > 0 ? bh % p.kv_heads : bh;   // head-parallel sharding: (source rank, head) pairs share K / V^T
+  const unsigned char* kptr = static_cast<const unsigned char*>(p.seg[0].k) + (int64_t)kvh * p.seg[0].nk_pad * RB;
+  const unsigned char* vptr = static_cast<const unsigned char*>(p.seg[0].vt) + (int64_t)kvh * OVG_D * p.seg[0].nk_pad * 2;
   int64_t vstride = p.seg[0].nk_pad * 2;          // bytes between V^T rows (d)
   auto fetch = [&]() {
 #pragma unroll
@@ -162,8 +163,8 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
       if (fseg < p.nseg) {
         const ovg_kv_segment sg = p.seg[fseg];
         f_ntiles = (int)((sg.nk + BC - 1) / BC);
-        kptr = static_cast<const unsigned char*>(sg.k) + (int64_t)bh * sg.nk_pad * RB;
-        vptr = static_cast<const unsigned char*>(sg.vt) + (int64_t)bh * OVG_D * sg.nk_pad * 2;
+        kptr = static_cast<const unsigned char*>(sg.k) + (int64_t)kvh * sg.nk_pad * RB;
+        vptr = static_cast<const unsigned char*>(sg.vt) + (int64_t)kvh * OVG_D * sg.nk_pad * 2;
         vstride = sg.nk_pad * 2;
       }
     }
@@ -343,7 +344,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn16_kernel(ovg_attn_params p
     const float inv = 1.0f / lacc[qb][0];        // every row of the ones-MFMA holds the full row sum
     const int q = q0 + qb * 16 + lr;
     if (q < nq) {
-      T* dst = static_cast<T*>(p.out) + ((int64_t)bq * nq + q) * p.ldo + hh * OVG_D + 4 * g;
+      T* dst = p.out_bh_stride > 0 ? static_cast<T*>(p.out) + (int64_t)bh * p.out_bh_stride + (int64_t)q * p.ldo + 4 * g
+                                   : static_cast<T*>(p.out) + ((int64_t)bq * nq + q) * p.ldo + hh * OVG_D + 4 * g;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
         store4<T>(dst + 16 * dt, o[qb][dt][0] * inv, o[qb][dt][1] * inv, o[qb][dt][2] * inv, o[qb][dt][3] * inv);

@@ -39,6 +39,8 @@ int run_prologue(const ovg_block_params* p, void* st, int part) {
 }
 
 int run_epilogue(const ovg_block_params* p, void* st) {
+  int rc = OVG_OK;
+  if (!p->skip_attention) {
   ovg_attn_params a{};
   a.q = p->ws_q; a.nq = p->seq; a.nq_pad = p->nq_pad;
   a.nseg = 1 + p->nseg_extra;
@@ -49,9 +51,10 @@ int run_epilogue(const ovg_block_params* p, void* st) {
   }
   a.out = p->ws_attn; a.ldo = OVG_C; a.BH = p->BH; a.dtype = p->dtype; a.variant = p->attn_variant;
   if (p->ev_attn_start) (void)hipEventRecord(static_cast<hipEvent_t>(p->ev_attn_start), static_cast<hipStream_t>(st));
-  int rc = ovg_flash_attn(&a, st);
+  rc = ovg_flash_attn(&a, st);
   if (p->ev_attn_stop) (void)hipEventRecord(static_cast<hipEvent_t>(p->ev_attn_stop), static_cast<hipStream_t>(st));
   if (rc) return rc;
+  }
 
   ovg_linear_params l{};
   l.x = p->ws_attn; l.ldx = OVG_C; l.w = p->w.proj_w; l.ldw = OVG_C; l.bias = p->w.proj_b;

@@ -205,6 +205,28 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
+// head-major [heads, n_pad, 64] -> token-major [n, heads*64]; one thread = 16 bytes (8 elements)
+__global__ __launch_bounds__(256) void heads_to_tokens_kernel(ovg_heads_to_tokens_params p, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c = (int)(idx & 7);                       // 16-byte chunk of the 64-wide head row
+    const int64_t t = idx >> 3;
+    const int h = (int)(t % p.heads);
+    const int64_t row = t / p.heads;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(p.x) + (((int64_t)h * p.n_pad + row) * 64 + c * 8) * 2);
+    *reinterpret_cast<u32x4*>(static_cast<unsigned char*>(p.y) + ((row * p.ldy) + h * 64 + c * 8) * 2) = v;
+  }
+}
+
+extern "C" int ovg_heads_to_tokens(const ovg_heads_to_tokens_params* p, void* stream) {
+  if (!p || !p->x || !p->y || p->n <= 0 || p->n_pad < p->n || p->heads <= 0 || p->ldy < p->heads * 64 || (p->ldy % 8)) return OVG_E_ARG;
+  if (p->dtype != OVG_BF16 && p->dtype != OVG_F16) return OVG_E_DTYPE;
+  if (!al16(p->x) || !al16(p->y)) return OVG_E_ARG;
+  const int64_t total = p->n * p->heads * 8;
+  OVG_LAUNCH(heads_to_tokens_kernel, dim3(grid_for(total, 256, 1 << 16)), dim3(256), 0, static_cast<hipStream_t>(stream), *p, total);
+  OVG_CHECK_LAUNCH();
+  return OVG_OK;
+}
+
 extern "C" int ovg_layernorm(const ovg_layernorm_params* p, void* stream) {
   if (!p || !p->x || !p->y || !p->weight || !p->bias || p->rows <= 0) return OVG_E_ARG;
   if (!al16(p->x) || !al16(p->y) || !al16(p->weight) || !al16(p->bias) || (p->ldx % 4) || (p->ldy % 4)) return OVG_E_ARG;

@@ -14,7 +14,7 @@ OVG_BF16, OVG_F16, OVG_F32 = 0, 1, 2
 EPI_STORE, EPI_GELU, EPI_RES, EPI_PATCH = 0, 1, 2, 3
 OVG_MAX_SEG = 8
 KV_TILE = 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ERRORS = {0: "OVG_OK", -1: "OVG_E_ARG", -2: "OVG_E_DTYPE", -3: "OVG_E_LAUNCH", -4: "OVG_E_UNSUPPORTED"}
 
@@ -47,7 +47,8 @@ class KvSegment(C.Structure):
 
 class AttnParams(C.Structure):
     _fields_ = [("q", vp), ("nq", i64), ("nq_pad", i64), ("seg", KvSegment * OVG_MAX_SEG), ("nseg", i32),
-                ("out", vp), ("ldo", i64), ("BH", i64), ("dtype", i32), ("variant", i32)]
+                ("out", vp), ("ldo", i64), ("BH", i64), ("dtype", i32), ("variant", i32),
+                ("kv_heads", i32), ("out_bh_stride", i64)]
 
 
 class BlockWeights(C.Structure):
@@ -66,7 +67,8 @@ class BlockParams(C.Structure):
                 ("inject", vp), ("inj_period", i64),
                 ("ws_xn", vp), ("ws_q", vp), ("ws_k", vp), ("ws_vt", vp), ("ws_attn", vp), ("ws_hid", vp),
                 ("extra", KvSegment * OVG_MAX_SEG), ("nseg_extra", i32), ("local_seg_index", i32),
-                ("attn_variant", i32), ("qkv_part", i32), ("ev_attn_start", vp), ("ev_attn_stop", vp)]
+                ("attn_variant", i32), ("qkv_part", i32), ("ev_attn_start", vp), ("ev_attn_stop", vp),
+                ("skip_attention", i32)]
 
 
 class Im2colParams(C.Structure):
@@ -117,6 +119,10 @@ class DptOutParams(C.Structure):
     _fields_ = [("h", vp), ("w2", vp), ("b2", vp), ("val", vp), ("conf", vp), ("npix", i64), ("out_dim", i32), ("activation", i32)]
 
 
+class HeadsToTokensParams(C.Structure):
+    _fields_ = [("x", vp), ("n_pad", i64), ("y", vp), ("ldy", i64), ("n", i64), ("heads", i32), ("dtype", i32)]
+
+
 class UnprojectParams(C.Structure):
     _fields_ = [("depth", vp), ("cam", vp), ("out", vp), ("S", i64), ("H", i32), ("W", i32)]
 
@@ -142,6 +148,7 @@ SYMBOLS = {
     "ovg_upsample": (i32, [C.POINTER(UpsampleParams), vp]),
     "ovg_dpt_out": (i32, [C.POINTER(DptOutParams), vp]),
     "ovg_unproject": (i32, [C.POINTER(UnprojectParams), vp]),
+    "ovg_heads_to_tokens": (i32, [C.POINTER(HeadsToTokensParams), vp]),
     "ovg_probe_mfma": (i32, [vp, vp, vp, i32, vp]),
     "ovg_debug_set": (i32, [i32, i32]),
 }

@@ -86,20 +86,38 @@ def qkv(x, w, bias, seq, dtype, q, k, vt, qk_norm=None, rope=None, tokens_per_vi
     L.call("ovg_qkv", p, _stream())
 
 
-def flash_attn(q, segments, nq, dtype, out=None, variant=0):
-    """q [BH,nq_pad,64]; segments: list of (k [BH,nk_pad,64], vt [BH,64,nk_pad], nk).
-    Returns out [B*nq, 1024] token-major."""
+def flash_attn(q, segments, nq, dtype, out=None, variant=0, kv_heads=0, head_major=False):
+    """q [BH,nq_pad,64]; segments: list of (k [BHkv,nk_pad,64], vt [BHkv,64,nk_pad], nk).
+    Returns out [B*nq, 1024] token-major, or with head_major=True out [BH, nq_pad, 64].
+    kv_heads > 0: the segments hold kv_heads heads and batch entry bh attends to head bh % kv_heads
+    (head-parallel sharding: the BH entries are (source rank, head) pairs)."""
     _chk_dev(q)
     BH = q.shape[0]
     if out is None:
-        out = torch.empty((BH // H) * nq, C, device=q.device, dtype=dtype)
+        out = (torch.empty(BH, q.shape[1], D, device=q.device, dtype=dtype) if head_major
+               else torch.empty((BH // H) * nq, C, device=q.device, dtype=dtype))
     p = L.AttnParams()
     p.q, p.nq, p.nq_pad, p.nseg = L.ptr(q), nq, q.shape[1], len(segments)
     for i, (k, vt, nk) in enumerate(segments):
         _chk_dev(k, vt)
         p.seg[i].k, p.seg[i].vt, p.seg[i].nk, p.seg[i].nk_pad = L.ptr(k), L.ptr(vt), nk, k.shape[1]
-    p.out, p.ldo, p.BH, p.dtype, p.variant = L.ptr(out), out.stride(0), BH, L.dtype_code(dtype), variant
+    p.out, p.BH, p.dtype, p.variant, p.kv_heads = L.ptr(out), BH, L.dtype_code(dtype), variant, kv_heads
+    if head_major:
+        p.ldo, p.out_bh_stride = out.stride(1), out.stride(0)
+    else:
+        p.ldo = out.stride(0)
     L.call("ovg_flash_attn", p, _stream())
+    return out
+
+
+def heads_to_tokens(x, n, dtype, out=None):
+    """x [heads, n_pad, 64] head-major -> out [n, heads*64] token-major (16-bit dtypes)."""
+    _chk_dev(x, out)
+    heads, n_pad = x.shape[0], x.shape[1]
+    if out is None:
+        out = torch.empty(n, heads * D, device=x.device, dtype=dtype)
+    p = L.HeadsToTokensParams(L.ptr(x), n_pad, L.ptr(out), out.stride(0), n, heads, L.dtype_code(dtype))
+    L.call("ovg_heads_to_tokens", p, _stream())
     return out
 
 

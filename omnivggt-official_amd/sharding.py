@@ -14,6 +14,17 @@ online softmax makes the result independent of how keys are split).
 Uneven S % world is handled by padding every rank's K/V^T buffer to the largest shard and
 passing the per-rank valid key count; the kernel masks each segment's tail.
 
+Head-parallel exchange (mode "heads", the default whenever the views split evenly and 16 % world == 0):
+the all-gather moves (world-1) x 45 MB INTO every rank per layer (~2 ms at the ~350 GB/s an 8-GPU xGMI
+all-gather sustains) against ~3.4 ms of attention, and nothing but the tiny Q projection can hide it.
+Instead each rank keeps all 16 heads of ITS tokens through the QKV GEMM, then three all-to-alls hand every
+rank the q, k, v^T of ALL tokens for ITS 16/world heads (a rank sends (world-1)/world of 67 MB, each peer
+pair exchanges 1/world of it over its own xGMI link), attention runs over 16 (source rank, head) batch
+entries with `world` K/V^T segments (`kv_heads`: entry bh reads head bh % (16/world)), and one all-to-all
+returns the head-major outputs: 4x fewer bytes per rank than the all-gather and every link busy at once.
+The q / k / v^T buffers are already head-major, so the send chunks are contiguous and the received K/V^T
+chunks are used in place as segments; only the returned O needs one head-major -> token-major copy.
+
 The numeric steps go through an *executor* (HipExecutor below); tests drive the same
 control flow over gloo on CPU with an oracle-backed executor (tests/test_sharding_gloo.py).
 """
@@ -97,10 +108,51 @@ class HipExecutor:
         L.call("ovg_block_attn_epilogue", p, torch.cuda.current_stream().cuda_stream)
 
 
-class ViewSharding:
-    """Attach to a ZeroAggregator (`agg.shard = ViewSharding(group)`) to run it view-sharded."""
+    # ---- head-parallel (all-to-all) global attention -----------------------------------------------------
+    def heads_workspaces(self, n_local, P):
+        """(frame workspace, global workspace with q/k/vt [16, pad, 64] of the LOCAL tokens, exchange buffers)."""
+        ws_f = self.agg.workspace(n_local * P, P, self.device)
+        ws_g = self.agg.workspace(n_local * P, n_local * P, self.device)
+        ex = {"q": torch.empty_like(ws_g.q), "k": torch.empty_like(ws_g.k), "vt": torch.empty_like(ws_g.vt),
+              "o": torch.empty_like(ws_g.q), "o_back": torch.empty_like(ws_g.q)}
+        return ws_f, ws_g, ex
 
-    def __init__(self, group=None, executor_factory=None, gather_output=False):
+    def global_qkv(self, i, ws, x_in, x_out):
+        from . import lib as L
+        p = self.pk["global"][i].params(ws, x_in, x_out, **self._geo())
+        p.qkv_part = 0
+        L.call("ovg_block_attn_prologue", p, torch.cuda.current_stream().cuda_stream)
+        return ws.q, ws.k, ws.vt
+
+    def head_attention(self, qr, kr, vr, out, n, world):
+        """qr / kr [world, 16/world, pad, 64], vr [world, 16/world, 64, pad] as received (flattened on dim 0)."""
+        hpr = qr.shape[0] // world
+        segs = [(kr[r * hpr:(r + 1) * hpr], vr[r * hpr:(r + 1) * hpr], n) for r in range(world)]
+        ev = self.agg.next_attention_events()
+        if ev is not None:
+            ev[0].record()
+        ops.flash_attn(qr, segs, n, self.agg.compute_dtype, out=out, variant=self.agg.attn_variant, kv_heads=hpr, head_major=True)
+        if ev is not None:
+            ev[1].record()
+        return out
+
+    def global_finish(self, i, ws, x_in, x_out, o_back, n):
+        from . import lib as L
+        ops.heads_to_tokens(o_back, n, self.agg.compute_dtype, out=ws.attn)
+        p = self.pk["global"][i].params(ws, x_in, x_out, **self._geo())
+        p.skip_attention = 1
+        L.call("ovg_block_attn_epilogue", p, torch.cuda.current_stream().cuda_stream)
+
+
+class ViewSharding:
+    """Attach to a ZeroAggregator (`agg.shard = ViewSharding(group)`) to run it view-sharded.
+    mode: "auto" (head-parallel all-to-all when the views split evenly and 16 % world == 0, else K/V all-gather),
+    "heads" or "allgather"."""
+
+    def __init__(self, group=None, executor_factory=None, gather_output=False, mode="auto"):
+        if mode not in ("auto", "heads", "allgather"):
+            raise ValueError("mode must be auto, heads or allgather")
+        self.mode = mode
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
@@ -126,6 +178,13 @@ class ViewSharding:
         n_local, max_local = hi - lo, max(h - l for l, h in parts)
         counts = [(h - l) * P for l, h in parts]
         ex = self.executor_factory(agg, images.device)
+        even = S % self.world == 0 and 16 % self.world == 0
+        if self.mode == "heads" and not even:
+            raise ValueError("head-parallel sharding needs S % world == 0 and 16 % world == 0")
+        f32_path = getattr(agg, "compute_dtype", None) == torch.float32     # heads_to_tokens is 16-bit only
+        if self.mode == "heads" or (self.mode == "auto" and even and self.world > 1 and not f32_path):
+            return self._forward_heads(agg, ex, images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index,
+                                       parts, lo, hi, P)
 
         with torch.no_grad():
             tokens0, tables = ex.embed((images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index), (lo, hi))
@@ -143,6 +202,32 @@ class ViewSharding:
                 wk.wait()
                 wv.wait()
                 ex.global_rest(i, ws_g, buf[:, :C], buf[:, C:], kg, vg, counts, self.rank)
+                x = buf[:, C:]
+            if self.gather_output:
+                outs = [self.gather_views(o, parts) for o in outs]
+        return outs, agg.patch_start_idx
+
+    def _forward_heads(self, agg, ex, images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index, parts, lo, hi, P):
+        """Head-parallel global attention: q / k / v^T all-to-all -> attention over this rank's heads for ALL
+        tokens -> all-to-all of the head-major outputs back to the token owners (module docstring)."""
+        n_local = hi - lo
+        n = n_local * P
+        a2a = lambda out, inp: dist.all_to_all_single(out, inp, group=self.group)
+        with torch.no_grad():
+            tokens0, tables = ex.embed((images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index), (lo, hi))
+            ws_f, ws_g, xb = ex.heads_workspaces(n_local, P)
+            outs = ex.new_outputs(n_local, P)
+            x = tokens0
+            for i in range(agg.depth):
+                buf = outs[i].view(n, 2 * C)
+                ex.frame_block(i, ws_f, x, buf[:, :C], tables[i + 1][lo:hi].contiguous(), P)
+                q, k, vt = ex.global_qkv(i, ws_g, buf[:, :C], buf[:, C:])
+                a2a(xb["q"], q)
+                a2a(xb["k"], k)
+                a2a(xb["vt"], vt)
+                ex.head_attention(xb["q"], xb["k"], xb["vt"], xb["o"], n, self.world)
+                a2a(xb["o_back"], xb["o"])
+                ex.global_finish(i, ws_g, buf[:, :C], buf[:, C:], xb["o_back"], n)
                 x = buf[:, C:]
             if self.gather_output:
                 outs = [self.gather_views(o, parts) for o in outs]

@@ -231,6 +231,28 @@ def test_attn(quick):
             for variant in variants:
                 out = ops.flash_attn(qd, segs, nq, dt, variant=variant)
                 report("attn_%s_%s_v%d" % (name, cname, variant), out, ref_tok, TOL[name])
+        # head-parallel sharding form: 16 batch entries = (source rank, head) pairs sharing this rank's kv_heads heads,
+        # `world` K / V^T segments, head-major output; then the head-major -> token-major copy
+        if name != "f32":
+            world, hpr, nq, nk = 2, 8, 333, 200
+            q = (rnd(world * hpr, nq, 64, g=g) * 1.2).to(dt)
+            ks = [rnd(hpr, nk, 64, g=g).to(dt) for _ in range(world)]
+            vs = [rnd(hpr, nk, 64, g=g).to(dt) for _ in range(world)]
+            kf, vf = torch.cat(ks, 1).float(), torch.cat(vs, 1).float()                      # [hpr, world*nk, 64]
+            ref = torch.stack([attn_reference(q[bh].float(), kf[bh % hpr], vf[bh % hpr]) for bh in range(world * hpr)])
+            qd, _, _ = ops.alloc_qkv(world * hpr, nq, 64, dt, DEV)
+            qd[:, :nq] = q.to(DEV)
+            segs = []
+            for kk, vv in zip(ks, vs):
+                _, kd, vtd = ops.alloc_qkv(hpr, 64, nk, dt, DEV)
+                kd[:, :nk] = kk.to(DEV)
+                vtd[:, :, :nk] = vv.transpose(1, 2).to(DEV)
+                segs.append((kd, vtd, nk))
+            for variant in (0, 1, 6, 21, 18):
+                out = ops.flash_attn(qd, segs, nq, dt, variant=variant, kv_heads=hpr, head_major=True)
+                report("attn_%s_headpar_v%d" % (name, variant), out[:, :nq], ref, TOL[name])
+            tok = ops.heads_to_tokens(out, nq, dt)
+            report("heads_to_tokens_%s" % name, tok, out[:, :nq].permute(1, 0, 2).reshape(nq, -1).float().cpu(), 1e-7)
         # forced-rescale cases: one key spikes against one query late in the sequence (the lazy
         # rescale branch of the tuned kernel fires mid-stream), and a slowly rising score ramp
         # (speculative kernel: spike 6 / ramp leave the f32 exponent window -> verified fallback path;

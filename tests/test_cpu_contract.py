@@ -57,7 +57,7 @@ def test_ctypes_struct_layout_matches_c():
              "ovg_dino_specials_params": L.DinoSpecialsParams, "ovg_assemble_params": L.AssembleParams,
              "ovg_copy_rows_params": L.CopyRowsParams, "ovg_head_layernorm_params": L.HeadLayerNormParams,
              "ovg_conv_params": L.ConvParams, "ovg_upsample_params": L.UpsampleParams, "ovg_dpt_out_params": L.DptOutParams,
-             "ovg_unproject_params": L.UnprojectParams}
+             "ovg_unproject_params": L.UnprojectParams, "ovg_heads_to_tokens_params": L.HeadsToTokensParams}
     src = '#include <stdio.h>\n#include "%s"\nint main(){\n' % HEADER
     for name in pairs:
         src += 'printf("%s %%zu\\n", sizeof(%s));\n' % (name, name)

@@ -92,9 +92,39 @@ class OracleExecutor:
         assert torch.equal(kg[rank], ws.k) and torch.equal(vg[rank], ws.vt)
         s = (ws.q[:, :n] @ keys.transpose(1, 2)) * math.log(2.0)
         o = (torch.softmax(s, dim=-1) @ vals).permute(1, 0, 2).reshape(n, 1024)
+        self._post(i, x_in, x_out, o)
+
+    def _post(self, i, x_in, x_out, o):
+        pre = "aggregator.global_blocks.%d" % i
         x = x_in + F.linear(o, self.sd[pre + ".attn.proj.weight"], self.sd[pre + ".attn.proj.bias"]) * self.sd[pre + ".ls1.gamma"]
         m = orc.mlp(orc.layer_norm(x, self.sd, pre + ".norm2", 1e-5), self.sd, pre + ".mlp")
         x_out.copy_(x + m * self.sd[pre + ".ls2.gamma"])
+
+    # ---- head-parallel (all-to-all) mode ----
+    def heads_workspaces(self, n_local, P):
+        ws, _ = self.workspaces(n_local, n_local, P)
+        ex = {"q": torch.full_like(ws.q, float("nan")), "k": torch.full_like(ws.k, float("nan")), "vt": torch.full_like(ws.vt, float("nan")),
+              "o": torch.full_like(ws.q, float("nan")), "o_back": torch.full_like(ws.q, float("nan"))}
+        return ws, ws, ex
+
+    def global_qkv(self, i, ws, x_in, x_out):
+        self.global_kv(i, ws, x_in, x_out)
+        ws.q.zero_()
+        ws.q[:, : self._q.shape[1]] = self._q
+        return ws.q, ws.k, ws.vt
+
+    def head_attention(self, qr, kr, vr, out, n, world):
+        hpr = qr.shape[0] // world
+        for bh in range(qr.shape[0]):
+            h = bh % hpr
+            keys = torch.cat([kr[r * hpr + h][:n] for r in range(world)], dim=0)
+            vals = torch.cat([vr[r * hpr + h][:, :n].t() for r in range(world)], dim=0)
+            s = (qr[bh][:n] @ keys.t()) * math.log(2.0)
+            out[bh][:n] = torch.softmax(s, dim=-1) @ vals
+        return out
+
+    def global_finish(self, i, ws, x_in, x_out, o_back, n):
+        self._post(i, x_in, x_out, o_back[:, :n].permute(1, 0, 2).reshape(n, 1024))
 
 
 class FakeAgg:
@@ -106,7 +136,7 @@ class FakeAgg:
         return self.grid_hw
 
 
-def _worker(rank, world, port, S, dgi, cgi, result_dir, hw=518):
+def _worker(rank, world, port, S, dgi, cgi, result_dir, hw=518, mode="auto"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 2) // world))
@@ -114,7 +144,7 @@ def _worker(rank, world, port, S, dgi, cgi, result_dir, hw=518):
     try:
         sd = common.reduced_state_dict(DEPTH, DINO)
         inp = orc.synthetic_inputs(S, hw=hw)
-        sh = sharding.ViewSharding(executor_factory=lambda agg, dev: OracleExecutor(sd, DEPTH), gather_output=True)
+        sh = sharding.ViewSharding(executor_factory=lambda agg, dev: OracleExecutor(sd, DEPTH), gather_output=True, mode=mode)
         outs, start = sh.forward(FakeAgg(), inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
         assert start == 5 and sh.last_partition == sharding.partition(S, world)
         if rank == 0:
@@ -129,11 +159,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("S,dgi,cgi,hw", [(3, [1], [0, 2], 518), (3, [0], [1], (266, 350))])
-def test_view_sharded_forward_matches_monolithic_oracle(tmp_path, S, dgi, cgi, hw):
-    """uneven 2-rank split of 3 views; the second case is a non-square, non-trained patch grid (19 x 25)."""
+@pytest.mark.parametrize("S,dgi,cgi,hw,mode", [(3, [1], [0, 2], 518, "auto"), (3, [0], [1], (266, 350), "allgather"),
+                                                 (2, [1], [0, 1], (266, 350), "auto"), (4, [0, 3], [1, 2], (210, 266), "heads")])
+def test_view_sharded_forward_matches_monolithic_oracle(tmp_path, S, dgi, cgi, hw, mode):
+    """2 ranks: uneven splits (3 views -> K/V all-gather path) and even splits (-> head-parallel all-to-all path,
+    8 heads per rank); non-square, non-trained patch grids in all but the first case."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), S, dgi, cgi, str(tmp_path), hw), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), S, dgi, cgi, str(tmp_path), hw, mode), nprocs=world, join=True)
     sharded = torch.load(os.path.join(str(tmp_path), "sharded.pt"))
     sd = common.reduced_state_dict(DEPTH, DINO)
     inp = orc.synthetic_inputs(S, hw=hw)
