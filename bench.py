@@ -11,7 +11,8 @@ Default workload at every N: 64 views, 518^2, images-only, bf16 -- BASELINE.json
 north star's scaling statement ("frames/sec at 1/2/4/8 GPUs ... on 64-view 518^2 synthetic input";
 SURVEY.md section 8d: "Config 4 ... also run G=1,2,4 for the scaling curve"), so `python bench.py --gpus N`
 for N=1,2,4,8 IS that strong-scaling curve ("scaling": "strong": total work fixed, views sharded
-over the ranks, K/V^T all-gather over RCCL).  At N=1 the same JSON line also carries `secondary`:
+over the ranks; global attention exchanged by the head-parallel all-to-all of sharding.py over RCCL, `--shard-mode allgather`
+selects the K/V^T all-gather form).  At N=1 the same JSON line also carries `secondary`:
 the 8-view configs[1] measurement (frames/s + roofline of the same kernel on that shape).
 --views S overrides the view count; --aux adds depth + camera tokens on every view (configs[2]).
 
@@ -77,6 +78,8 @@ def main():
     ap.add_argument("--e2e", action="store_true", help="also time OmniVGGT.forward incl. the PyTorch heads (MIOpen JIT makes the first call slow)")
     ap.add_argument("--attn-variant", type=int, default=0)
     ap.add_argument("--aux", action="store_true", help="depth + camera tokens on every view (BASELINE configs[2] with --views 16)")
+    ap.add_argument("--shard-mode", default="auto", choices=["auto", "heads", "allgather"],
+                    help="N > 1: exchange form of the global attention (sharding.ViewSharding)")
     ap.add_argument("--partial-aux", action="store_true", help="cameras on the even views, depth on the second half of the views "
                     "(BASELINE configs[4] with --views 128 --dtype f16)")
     args = ap.parse_args()
@@ -109,7 +112,7 @@ def main():
     agg.attn_variant = args.attn_variant
     if world > 1:
         from omnivggt_official_amd.sharding import ViewSharding
-        agg.shard = ViewSharding(gather_output=False)
+        agg.shard = ViewSharding(gather_output=False, mode=args.shard_mode)
     def measure(S, steps, warmup):
         """Time `steps` aggregator forwards on S views; returns the result dict (rank-reduced)."""
         inp = synthetic_inputs(S, dev, aux=args.aux or args.partial_aux)
@@ -153,7 +156,9 @@ def main():
             "config": {"workload": "OmniVGGT aggregator forward, %d views 518x518 %s (BASELINE configs[%s]), view-sharded over %d GPU(s)"
                                    % (S, "+ depth + camera tokens" if args.aux else ("+ partial aux (cameras on even views, depth on the second half)" if args.partial_aux else "images-only"), cfg, world),
                        "views": S, "views_per_gpu": n_local, "tokens": S * P_TOK, "weights": "seeded synthetic (no checkpoint offline)",
-                       "parallelism": "view-shard x%d" % world},
+                       "parallelism": "view-shard x%d%s" % (world, "" if world == 1 else
+                                                            (", " + ("head-parallel all-to-all" if (args.shard_mode != "allgather" and S % world == 0 and 16 % world == 0
+                                                                                                    and args.dtype != "f32") else "K/V all-gather")))},
             "algorithmic_tflop_per_step": round(f_total / 1e12, 2),
             "tflops_per_gpu": round(f_total / 1e12 / (dt / steps) / world, 1),
             "roofline": {"bound": "mfma", "kernel": ({"bf16": "attn16_kernel<bf16,QB=4,WAVES=4,MODE=0> (speculative anchored softmax + verified fallback)",
