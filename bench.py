@@ -113,6 +113,8 @@ def main():
     if world > 1:
         from omnivggt_official_amd.sharding import ViewSharding
         agg.shard = ViewSharding(gather_output=False, mode=args.shard_mode)
+    shard_note = {}
+
     def measure(S, steps, warmup):
         """Time `steps` aggregator forwards on S views; returns the result dict (rank-reduced)."""
         inp = synthetic_inputs(S, dev, aux=args.aux or args.partial_aux)
@@ -130,6 +132,11 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
+        # N > 1, automatic exchange form: before timing anything, run the K/V all-gather form and the head-parallel
+        # all-to-all form once each on this workload and compare (ViewSharding.choose_mode); all ranks agree on which
+        # one may be used, and the JSON line says which one was timed (never part of `value`)
+        if dist is not None and args.shard_mode == "auto" and args.dtype != "f32":
+            shard_note.update(agg.shard.choose_mode(lambda: step()[0][-1], S))
         for _ in range(warmup):
             step()
         agg.reset_attention_events()
@@ -177,6 +184,9 @@ def main():
               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": primary["ms_per_step"],
               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic"}
     result.update({k: primary[k] for k in ("config", "algorithmic_tflop_per_step", "tflops_per_gpu", "roofline")})
+    if shard_note:
+        result["config"]["parallelism"] = "view-shard x%d, %s" % (world, shard_note.get("exchange", "?"))
+        result["shard_selfcheck"] = shard_note
     if world == 1 and S != 8 and not args.views:
         sec = measure(8, 10, 3)                                      # BASELINE configs[1] on the same process
         result["secondary"] = {"frames_per_s": sec["value"], "ms_per_step": sec["ms_per_step"], "config": sec["config"],

@@ -162,6 +162,35 @@ class ViewSharding:
         self.gather_output = gather_output
         self.last_partition = None
 
+    def choose_mode(self, run, n_views, tol=5e-2):
+        """Self-check for mode "auto": `run()` must execute one sharded forward and return a tensor of it (e.g. the
+        last layer). Runs the K/V all-gather form and the head-parallel all-to-all form once each, compares them, lets
+        all ranks agree (MAX all-reduce of a failure flag) and pins `self.mode` to the all-to-all form only if it ran
+        and matched. Returns a small report dict."""
+        report = {}
+        if n_views % self.world != 0 or 16 % self.world != 0:
+            self.mode = "allgather"
+            report["exchange"] = "K/V all-gather"
+            return report
+        self.mode = "allgather"
+        ref = run().float().clone()
+        self.mode = "heads"
+        bad = torch.zeros(1, device=ref.device)
+        err = float("nan")
+        try:
+            got = run().float()
+            err = float((got - ref).abs().max() / ref.abs().max().clamp(min=1e-30))
+            bad[0] = 0.0 if err < tol else 1.0
+        except Exception as e:                             # only on a broken collective / kernel
+            bad[0] = 1.0
+            report["error"] = repr(e)[:200]
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
+        if float(bad.item()) > 0:
+            self.mode = "allgather"
+        report["selfcheck_max_rel_vs_allgather"] = err
+        report["exchange"] = "K/V all-gather" if self.mode == "allgather" else "head-parallel all-to-all"
+        return report
+
     def forward(self, agg, images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index):
         B, S = images.shape[:2]
         if B != 1:

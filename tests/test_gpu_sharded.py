@@ -64,6 +64,10 @@ def test_world_size_one_rccl_matches_unsharded():
             got2, _ = m.aggregator(*args)
         for a, b in zip(got2, ref):
             assert common.max_rel(a.cpu(), b.cpu()) <= 1e-6
+        # bench.py's self-check that picks the exchange form
+        rep = m.aggregator.shard.choose_mode(lambda: m.aggregator(*args)[0][-1], S)
+        assert rep["exchange"] == "head-parallel all-to-all" and rep["selfcheck_max_rel_vs_allgather"] <= 1e-6
+        assert m.aggregator.shard.mode == "heads"
     finally:
         m.aggregator.shard = None
         dist.destroy_process_group()

@@ -144,8 +144,15 @@ def _worker(rank, world, port, S, dgi, cgi, result_dir, hw=518, mode="auto"):
     try:
         sd = common.reduced_state_dict(DEPTH, DINO)
         inp = orc.synthetic_inputs(S, hw=hw)
-        sh = sharding.ViewSharding(executor_factory=lambda agg, dev: OracleExecutor(sd, DEPTH), gather_output=True, mode=mode)
-        outs, start = sh.forward(FakeAgg(), inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
+        sh = sharding.ViewSharding(executor_factory=lambda agg, dev: OracleExecutor(sd, DEPTH), gather_output=True,
+                                   mode="auto" if mode == "choose" else mode)
+        fa = FakeAgg()
+        fwd = lambda: sh.forward(fa, inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
+        if mode == "choose":                           # bench.py's self-check: both exchange forms, agree, pin the all-to-all
+            rep = sh.choose_mode(lambda: fwd()[0][-1], S)
+            assert rep["exchange"] == "head-parallel all-to-all" and rep["selfcheck_max_rel_vs_allgather"] < 1e-5, rep
+            assert sh.mode == "heads"
+        outs, start = fwd()
         assert start == 5 and sh.last_partition == sharding.partition(S, world)
         if rank == 0:
             torch.save([o.clone() for o in outs], os.path.join(result_dir, "sharded.pt"))
@@ -160,7 +167,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("S,dgi,cgi,hw,mode", [(3, [1], [0, 2], 518, "auto"), (3, [0], [1], (266, 350), "allgather"),
-                                                 (2, [1], [0, 1], (266, 350), "auto"), (4, [0, 3], [1, 2], (210, 266), "heads")])
+                                                 (2, [1], [0, 1], (266, 350), "choose"), (4, [0, 3], [1, 2], (210, 266), "heads")])
 def test_view_sharded_forward_matches_monolithic_oracle(tmp_path, S, dgi, cgi, hw, mode):
     """2 ranks: uneven splits (3 views -> K/V all-gather path) and even splits (-> head-parallel all-to-all path,
     8 heads per rank); non-square, non-trained patch grids in all but the first case."""
