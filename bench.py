@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--e2e", action="store_true", help="also time OmniVGGT.forward incl. the PyTorch heads (MIOpen JIT makes the first call slow)")
     ap.add_argument("--attn-variant", type=int, default=0)
     ap.add_argument("--aux", action="store_true", help="depth + camera tokens on every view (BASELINE configs[2] with --views 16)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N > 1: torch.distributed backend (nccl = RCCL; gloo only for debugging, e.g. several ranks on one GPU)")
     ap.add_argument("--shard-mode", default="auto", choices=["auto", "heads", "allgather"],
                     help="N > 1: exchange form of the global attention (sharding.ViewSharding)")
     ap.add_argument("--partial-aux", action="store_true", help="cameras on the even views, depth on the second half of the views "
@@ -92,13 +94,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (one process per GPU)" % args.gpus)
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     L.require_gpu()
+    if os.environ.get("OVG_FORCE_DEVICE"):      # debugging aid: several ranks on one GPU (only if the RCCL build accepts it)
+        local = int(os.environ["OVG_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:                                     # host backend: ViewSharding stages its collectives through the host
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     dtype = DT[args.dtype]
     with torch.device("meta"):
@@ -150,7 +157,7 @@ def main():
         agg.disable_attention_events()
         attn_avg_ms = sum(attn_ms) / max(len(attn_ms), 1)
         if dist is not None:
-            t = torch.tensor([dt, attn_avg_ms], device=dev, dtype=torch.float64)
+            t = torch.tensor([dt, attn_avg_ms], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt, attn_avg_ms = float(t[0].item()), float(t[1].item())
         f_total, f_ga = agg_flops(S)

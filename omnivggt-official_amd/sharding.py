@@ -162,6 +162,40 @@ class ViewSharding:
         self.gather_output = gather_output
         self.last_partition = None
 
+    # ---- collectives: RCCL on device tensors; with a host backend (gloo) device tensors are staged through the
+    #      host, so the same control flow also runs where RCCL cannot (tests, several ranks sharing one GPU) -------
+    class _Done:
+        def wait(self):
+            return None
+
+    def _staged(self, t):
+        return t.is_cuda and dist.get_backend(self.group) != "nccl"
+
+    def _all_gather(self, out, inp, async_op=False):
+        if self._staged(inp):
+            tmp = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(tmp, inp.cpu(), group=self.group)
+            out.copy_(tmp)
+            return self._Done()
+        w = dist.all_gather_into_tensor(out, inp, group=self.group, async_op=async_op)
+        return w if async_op else self._Done()
+
+    def _all_to_all(self, out, inp):
+        if self._staged(inp):
+            tmp = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(tmp, inp.cpu(), group=self.group)
+            out.copy_(tmp)
+        else:
+            dist.all_to_all_single(out, inp, group=self.group)
+
+    def _all_reduce_max(self, t):
+        if self._staged(t):
+            tmp = t.cpu()
+            dist.all_reduce(tmp, op=dist.ReduceOp.MAX, group=self.group)
+            t.copy_(tmp)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+
     def choose_mode(self, run, n_views, tol=5e-2):
         """Self-check for mode "auto": `run()` must execute one sharded forward and return a tensor of it (e.g. the
         last layer). Runs the K/V all-gather form and the head-parallel all-to-all form once each, compares them, lets
@@ -184,7 +218,7 @@ class ViewSharding:
         except Exception as e:                             # only on a broken collective / kernel
             bad[0] = 1.0
             report["error"] = repr(e)[:200]
-        dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
+        self._all_reduce_max(bad)
         if float(bad.item()) > 0:
             self.mode = "allgather"
         report["selfcheck_max_rel_vs_allgather"] = err
@@ -225,8 +259,8 @@ class ViewSharding:
                 buf = outs[i].view(n_local * P, 2 * C)
                 ex.frame_block(i, ws_f, x, buf[:, :C], tables[i + 1][lo:hi].contiguous(), P)
                 k_loc, vt_loc = ex.global_kv(i, ws_g, buf[:, :C], buf[:, C:])
-                wk = dist.all_gather_into_tensor(kg.flatten(0, 1), k_loc, group=self.group, async_op=True)
-                wv = dist.all_gather_into_tensor(vg.flatten(0, 1), vt_loc, group=self.group, async_op=True)
+                wk = self._all_gather(kg.flatten(0, 1), k_loc, async_op=True)
+                wv = self._all_gather(vg.flatten(0, 1), vt_loc, async_op=True)
                 ex.global_q(i, ws_g, buf[:, :C], buf[:, C:])          # overlaps the all-gather
                 wk.wait()
                 wv.wait()
@@ -241,7 +275,7 @@ class ViewSharding:
         tokens -> all-to-all of the head-major outputs back to the token owners (module docstring)."""
         n_local = hi - lo
         n = n_local * P
-        a2a = lambda out, inp: dist.all_to_all_single(out, inp, group=self.group)
+        a2a = self._all_to_all
         with torch.no_grad():
             tokens0, tables = ex.embed((images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index), (lo, hi))
             ws_f, ws_g, xb = ex.heads_workspaces(n_local, P)
@@ -268,5 +302,5 @@ class ViewSharding:
         pad = torch.zeros((1, max_local) + tuple(local.shape[2:]), device=local.device, dtype=local.dtype)
         pad[:, : local.shape[1]] = local
         full = torch.empty((self.world,) + tuple(pad.shape), device=local.device, dtype=local.dtype)
-        dist.all_gather_into_tensor(full.flatten(0, 1), pad, group=self.group)
+        self._all_gather(full.flatten(0, 1), pad)
         return torch.cat([full[r][:, : h - l] for r, (l, h) in enumerate(parts)], dim=1)
