@@ -19,7 +19,9 @@
  *     (parity mode, exact-f32 MFMA).  The residual stream, LayerNorm
  *     statistics, softmax statistics, biases, LayerScale gammas, q/k-norm
  *     affine parameters and the RoPE table are always f32.
- *   - thread-safe for distinct streams; no global mutable state.
+ *   - thread-safe for distinct streams; the library holds NO mutable state: every tuning choice is either
+ *     derived from the call's shapes or passed in the parameter struct (`tile`, `variant`).
+ *   - workspace is caller-provided; ovg_block_workspace_bytes() answers how much a block call needs.
  */
 #ifndef OMNIVGGT_HIP_H
 #define OMNIVGGT_HIP_H
@@ -30,9 +32,13 @@
 extern "C" {
 #endif
 
-/* 2: + DPT-head entries (ovg_head_layernorm, ovg_conv, ovg_upsample, ovg_dpt_out) and ovg_unproject
- * 3: + head-parallel sharding (ovg_attn_params.kv_heads / out_bh_stride, ovg_block_params.skip_attention, ovg_heads_to_tokens) */
-#define OVG_ABI_VERSION 3
+/* ABI history
+ * 2: + DPT-head entries (ovg_head_layernorm, ovg_conv, ovg_upsample, ovg_dpt_out) and ovg_unproject
+ * 3: + head-parallel sharding (ovg_attn_params.kv_heads / out_bh_stride, ovg_block_params.skip_attention, ovg_heads_to_tokens)
+ * 4: per-call GEMM tile selector (`tile`) replacing the process-global debug setter of ABI 3, optional
+ *    log-sum-exp output of ovg_flash_attn + ovg_attn_merge (two-launch local-first sharded attention),
+ *    ovg_block_workspace_bytes, ovg_pack_weights */
+#define OVG_ABI_VERSION 4
 
 enum { OVG_BF16 = 0, OVG_F16 = 1, OVG_F32 = 2 };
 
@@ -84,6 +90,9 @@ int ovg_layernorm(const ovg_layernorm_params*, void* stream);
  *                   (patch_embed.py:75-77 + vision_transformer.py:220-224)
  * ------------------------------------------------------------------ */
 enum { OVG_EPI_STORE = 0, OVG_EPI_GELU = 1, OVG_EPI_RES = 2, OVG_EPI_PATCH = 3 };
+/* workgroup tile of the GEMM kernels: 128 x 128 (4 waves, register-staged, 2 workgroups per CU) or 256 x 256
+ * (8 waves, LDS-DMA ring, 16-bit dtypes); AUTO picks by shape (ovg_gemm.hip: use_256) */
+enum { OVG_TILE_AUTO = 0, OVG_TILE_128 = 1, OVG_TILE_256 = 2 };
 typedef struct {
   const void* x; int64_t ldx;
   const void* w; int64_t ldw;
@@ -96,6 +105,7 @@ typedef struct {
   const float* inject; int64_t inj_period;   /* inject may be NULL */
   /* PATCH */
   const float* table; int64_t p0; int64_t p1; int64_t row_off;
+  int tile;   /* OVG_TILE_AUTO (shape heuristic), OVG_TILE_128 or OVG_TILE_256 (16-bit dtypes, N % 256 == 0; else OVG_E_ARG) */
 } ovg_linear_params;
 int ovg_linear(const ovg_linear_params*, void* stream);
 
@@ -122,6 +132,7 @@ typedef struct {
   int64_t tokens_per_view; int grid_w; int n_special;
   float q_scale;
   int part;   /* 0 = q,k,v; 1 = k and v only; 2 = q only (sharded path: K/V first, all-gather || Q) */
+  int tile;   /* OVG_TILE_* as in ovg_linear_params */
 } ovg_qkv_params;
 int ovg_qkv(const ovg_qkv_params*, void* stream);
 
@@ -148,8 +159,24 @@ typedef struct {
    *   out_bh_stride > 0: head-major output, out + bh * out_bh_stride + q * ldo + d (ldo >= 64) instead of the
    *                 token-major row (bh / 16) * nq + q, column (bh % 16) * 64 + d. */
   int kv_heads; int64_t out_bh_stride;
+  /* optional f32 [BH, nq_pad]: lse[bh, q] = log2(sum_k exp2(s[q, k])) over the keys of THIS call (s = the
+   * pre-scaled logits). With it, two calls over disjoint key sets are combined exactly by ovg_attn_merge --
+   * the view-sharded all-gather path runs the local keys while the remote ones are still in flight. */
+  float* lse;
 } ovg_attn_params;
 int ovg_flash_attn(const ovg_attn_params*, void* stream);
+
+/* Combine two attention results over disjoint key sets (same queries):
+ *   w_a = 2^(lse_a - m), w_b = 2^(lse_b - m), m = max(lse_a, lse_b);  out = (w_a * a + w_b * b) / (w_a + w_b)
+ * a, b, out: [rows, 1024] `dtype` token-major (row strides lda / ldb / ldo; out may alias a or b);
+ * lse_a, lse_b: f32 [16, n_pad] head-major as written by ovg_flash_attn (row = token n, B = 1). */
+typedef struct {
+  const void* a; int64_t lda; const float* lse_a;
+  const void* b; int64_t ldb; const float* lse_b;
+  void* out; int64_t ldo;
+  int64_t rows; int64_t n_pad; int dtype;
+} ovg_attn_merge_params;
+int ovg_attn_merge(const ovg_attn_merge_params*, void* stream);
 
 /* ------------------------------------------------------------------ *
  * One pre-LN transformer block (block.py:81-107):
@@ -197,6 +224,7 @@ typedef struct {
    * flash-attention launch (bench.py: live per-kernel timing); NULL = not recorded */
   void* ev_attn_start; void* ev_attn_stop;
   int skip_attention;  /* ovg_block_attn_epilogue only: ws_attn already holds the attention output (head-parallel sharding) */
+  int gemm_tile;       /* OVG_TILE_* forwarded to the four GEMMs of the block (tests force a tile; 0 in production) */
 } ovg_block_params;
 /* whole block */
 int ovg_block_forward(const ovg_block_params*, void* stream);
@@ -204,6 +232,20 @@ int ovg_block_forward(const ovg_block_params*, void* stream);
  * epilogue = attention (over local+extra segments) + proj + MLP. */
 int ovg_block_attn_prologue(const ovg_block_params*, void* stream);
 int ovg_block_attn_epilogue(const ovg_block_params*, void* stream);
+
+/* Workspace query (host only, no device work): bytes of each caller-provided scratch buffer of a block call
+ * with the given M, seq, BH, nq_pad, nk_pad and dtype (all other fields ignored). */
+typedef struct { int64_t xn, q, k, vt, attn, hid, total; } ovg_block_workspace;
+int ovg_block_workspace_bytes(const ovg_block_params*, ovg_block_workspace* out);
+
+/* Weight pre-pack (inference.py:321-325 loads f32 checkpoints): dst[r, :k] = convert(src[r, :k]) to `dtype`,
+ * dst[r, k:k_pad] = 0.  src f32 [rows, k] (ld lds), dst `dtype` [rows, k_pad] (ld ldd, k_pad % 8 == 0).
+ * nn.Linear weights pack with k_pad = k; the Conv2d(k=14,s=14) patch weights with k = C_in*196, k_pad = 640 / 448. */
+typedef struct {
+  const float* src; int64_t lds; void* dst; int64_t ldd;
+  int64_t rows; int64_t k; int64_t k_pad; int dtype;
+} ovg_pack_weights_params;
+int ovg_pack_weights(const ovg_pack_weights_params*, void* stream);
 
 /* ------------------------------------------------------------------ *
  * Patch im2col (Conv2d k=14,s=14 as a GEMM: patch_embed.py:65,75-77).
@@ -362,13 +404,6 @@ int ovg_heads_to_tokens(const ovg_heads_to_tokens_params*, void* stream);
  * acc of one 16x16 MFMA for dtype given raw 16-byte A/B fragments per lane. */
 int ovg_probe_mfma(const void* a_frag, const void* b_frag, float* out, int dtype, void* stream);
 
-/* Benchmarking knobs (process-global, not thread-safe, never needed for correctness):
- * key 0 = GEMM tile-order group size of the 128x128 kernels (0 = n-fastest, default 8 = grouped, see ovg_gemm.hip);
- * key 1 = GEMM main loop: 0 automatic choice between the 128x128 register-staged and the 256x256 ping-pong
- *         loop (default), 1 = 128x128 LDS-DMA, 2/3 = its diagnostic ablations, 4 = force 256x256 where legal,
- *         5/6 = its diagnostic ablations, 7 = force 128x128;
- * key 2 = tile-order group size of the 256x256 kernels (default 4). */
-int ovg_debug_set(int key, int value);
 
 #ifdef __cplusplus
 }

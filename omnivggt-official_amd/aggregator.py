@@ -90,13 +90,20 @@ class DinoParams(nn.Module):
 # ----------------------------------------------------------------------------
 class Workspace:
     """Scratch for one (tokens, sequence length) shape."""
-    def __init__(self, M, seq, dtype, device):
+    def __init__(self, M, seq, dtype, device, share=None, kv_rows=None):
+        """share: another Workspace with the same M whose LN / attention / hidden scratch is reused (nothing is
+        allocated twice); kv_rows: pad q / k / v^T to this many rows instead of `seq` (sharded path: all ranks
+        gather equal-sized buffers). Sizes equal ovg_block_workspace_bytes() for (M, seq, dtype)."""
         self.M, self.seq, self.dtype = M, seq, dtype
         self.BH = (M // seq) * HEADS
-        self.xn = torch.empty(M, C, device=device, dtype=dtype)
-        self.attn = torch.empty(M, C, device=device, dtype=dtype)
-        self.hid = torch.empty(M, 4 * C, device=device, dtype=dtype)
-        self.q, self.k, self.vt = ops.alloc_qkv(self.BH, seq, seq, dtype, device)
+        if share is not None:
+            self.xn, self.attn, self.hid = share.xn, share.attn, share.hid
+        else:
+            self.xn = torch.empty(M, C, device=device, dtype=dtype)
+            self.attn = torch.empty(M, C, device=device, dtype=dtype)
+            self.hid = torch.empty(M, 4 * C, device=device, dtype=dtype)
+        rows = seq if kv_rows is None else kv_rows
+        self.q, self.k, self.vt = ops.alloc_qkv(self.BH, rows, rows, dtype, device)
 
     def share_from(self, other):
         """Reuse the LN / attention / hidden scratch of another workspace with the same M."""
@@ -108,13 +115,19 @@ class BlockRunner:
     """Packed weights of one block + the ovg_block_forward call."""
     _GEMM = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")
 
-    def __init__(self, sd, prefix, dtype, device, qk_norm, rope, ln_eps, rope_tables=None, attn_variant=0):
+    def __init__(self, sd, prefix, dtype, device, qk_norm, rope, ln_eps, rope_tables=None, knobs=None):
         self.dtype, self.qk_norm, self.rope, self.ln_eps = dtype, qk_norm, rope, ln_eps
-        self.attn_variant = attn_variant
+        # `knobs`: any object with .attn_variant / .gemm_tile, read at CALL time (the aggregator itself), so that
+        # changing agg.attn_variant after pack() takes effect; None = library defaults
+        self.knobs = knobs
         t = {}
 
         def grab(name, dt):
-            t[name] = sd["%s.%s" % (prefix, name)].detach().to(device=device, dtype=dt).contiguous()
+            src = sd["%s.%s" % (prefix, name)].detach()
+            if name in self._GEMM and dt != torch.float32 and src.dtype == torch.float32:
+                t[name] = ops.pack_weights(src.to(device), dt)       # ovg_pack_weights: f32 checkpoint -> compute dtype
+            else:
+                t[name] = src.to(device=device, dtype=dt).contiguous()
             return L.ptr(t[name])
 
         w = L.BlockWeights()
@@ -149,7 +162,8 @@ class BlockRunner:
             p.inject, p.inj_period = L.ptr(inject), inj_period
         p.ws_xn, p.ws_q, p.ws_k, p.ws_vt, p.ws_attn, p.ws_hid = (L.ptr(ws.xn), L.ptr(ws.q), L.ptr(ws.k), L.ptr(ws.vt),
                                                                   L.ptr(ws.attn), L.ptr(ws.hid))
-        p.attn_variant = self.attn_variant
+        p.attn_variant = int(getattr(self.knobs, "attn_variant", 0))
+        p.gemm_tile = int(getattr(self.knobs, "gemm_tile", 0))
         return p
 
     def forward(self, ws, x_in, x_out, inject=None, inj_period=0, events=None, **kw):
@@ -176,10 +190,12 @@ class ZeroAggregator(nn.Module):
     def __init__(self, img_size=518, patch_size=14, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4,
                  num_register_tokens=4, pose_hidden_dim=512, patch_embed="dinov2_vitl14_reg", aa_order=("frame", "global"),
                  aa_block_size=1, qk_norm=True, rope_freq=100, init_values=0.01, dino_depth=24,
-                 compute_dtype=torch.bfloat16, **unused):
+                 compute_dtype=torch.float32, **unused):
         super().__init__()
         if embed_dim != C or num_heads != HEADS or patch_size != 14 or mlp_ratio != 4:
             raise ValueError("the gfx950 kernels are built for embed_dim=1024, 16 heads, patch 14, mlp_ratio 4")
+        if pose_hidden_dim <= 0:
+            raise ValueError("pose_hidden_dim must be positive")
         if patch_embed != "dinov2_vitl14_reg" or tuple(aa_order) != ("frame", "global") or aa_block_size != 1 or not qk_norm or rope_freq <= 0:
             raise ValueError("unsupported aggregator configuration for the HIP path")
         self.img_size, self.patch_size, self.depth, self.dino_depth = img_size, patch_size, depth, dino_depth
@@ -203,8 +219,11 @@ class ZeroAggregator(nn.Module):
             nn.init.zeros_(a.bias)
         self.depth_patch_embed = _ConvProj(2, embed_dim)
         self.pose_hidden_dim = pose_hidden_dim
+        self.pose_k_pad = (pose_hidden_dim + 63) // 64 * 64     # K of the stacked pose-embedding GEMM (ovg_linear: K % 64 == 0)
         self.compute_dtype = compute_dtype
-        self.attn_variant = 0
+        self.attn_variant = 0       # ovg_attn_params.variant of every attention call (0 = library default); read per call
+        self.gemm_tile = 0          # OVG_TILE_* forced on the block GEMMs (tests); 0 = shape heuristic
+        self.max_workspaces = 4     # scratch shapes kept alive (frame + global of the two most recent geometries)
         self.shard = None           # set by sharding.ViewSharding for the multi-GPU path
         self._packed = None
         self._ws = {}
@@ -213,31 +232,37 @@ class ZeroAggregator(nn.Module):
     # ------------------------------------------------------------------
     # live per-kernel timing of the global-attention launches (bench.py roofline)
     def enable_attention_events(self, n):
+        """Pre-create n HIP event pairs; every global-attention launch takes the next pair (None when exhausted)."""
         self._events = []
         for _ in range(n):
             pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             pair[0].record()
             pair[1].record()          # materialise the hipEvent_t handles
             self._events.append(pair)
-        self._event_i = 0
+        self._event_i, self._event_flop = 0, []
         return self._events
 
     def reset_attention_events(self):
-        self._event_i = 0
+        self._event_i, self._event_flop = 0, []
 
-    def next_attention_events(self):
+    def next_attention_events(self, flop=0.0):
+        """Event pair for the next global-attention launch; `flop` = algorithmic FLOP of that launch (4 * BH * nq * nk * 64)."""
         ev = getattr(self, "_events", None)
         if not ev or self._event_i >= len(ev):
             return None
         self._event_i += 1
+        self._event_flop.append(float(flop))
         return ev[self._event_i - 1]
 
     def attention_event_times(self):
         """ms of every recorded global-attention launch since reset (device must be synchronised)."""
         return [a.elapsed_time(b) for a, b in getattr(self, "_events", [])[: getattr(self, "_event_i", 0)]]
 
+    def attention_event_flops(self):
+        return list(getattr(self, "_event_flop", []))
+
     def disable_attention_events(self):
-        self._events, self._event_i = [], 0
+        self._events, self._event_i, self._event_flop = [], 0, []
 
     def invalidate(self):
         self._packed = None
@@ -292,16 +317,12 @@ class ZeroAggregator(nn.Module):
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         rope = make_rope_tables(ROPE_MAX_POS, device, self.rope_freq)
         pk = {"device": device, "dtype": dt, "rope": rope}
-        pk["dino"] = [BlockRunner(sd, "patch_embed.blocks.%d" % i, dt, device, False, False, 1e-6, attn_variant=self.attn_variant)
-                      for i in range(self.dino_depth)]
-        pk["frame"] = [BlockRunner(sd, "frame_blocks.%d" % i, dt, device, True, True, 1e-5, rope, self.attn_variant) for i in range(self.depth)]
-        pk["global"] = [BlockRunner(sd, "global_blocks.%d" % i, dt, device, True, True, 1e-5, rope, self.attn_variant) for i in range(self.depth)]
+        pk["dino"] = [BlockRunner(sd, "patch_embed.blocks.%d" % i, dt, device, False, False, 1e-6, knobs=self) for i in range(self.dino_depth)]
+        pk["frame"] = [BlockRunner(sd, "frame_blocks.%d" % i, dt, device, True, True, 1e-5, rope, knobs=self) for i in range(self.depth)]
+        pk["global"] = [BlockRunner(sd, "global_blocks.%d" % i, dt, device, True, True, 1e-5, rope, knobs=self) for i in range(self.depth)]
 
-        def conv_as_gemm(w, k_pad):
-            w2 = w.detach().reshape(w.shape[0], -1)
-            out = torch.zeros(w.shape[0], k_pad, dtype=torch.float32)
-            out[:, : w2.shape[1]] = w2.float().cpu()
-            return out.to(device=device, dtype=dt).contiguous()
+        def conv_as_gemm(w, k_pad):          # Conv2d(k=14, s=14) weight [1024, C_in, 14, 14] -> GEMM rows [1024, k_pad]
+            return ops.pack_weights(w.detach().to(device), dt, k_pad=k_pad)
 
         pk["patch_w"] = conv_as_gemm(sd["patch_embed.patch_embed.proj.weight"], 640)
         pk["patch_b"] = f32(sd["patch_embed.patch_embed.proj.bias"])
@@ -316,7 +337,7 @@ class ZeroAggregator(nn.Module):
         pk["placeholder"] = f32(sd["depth_placeholder"].reshape(-1))
         # camera modality tables (exact f32 MFMA path): all pose embeddings stacked into one GEMM
         G = self.depth + 1
-        pe_w = torch.zeros(G * C, 64)
+        pe_w = torch.zeros(G * C, self.pose_k_pad)
         for i in range(G):
             pe_w[i * C:(i + 1) * C, : self.pose_hidden_dim] = sd["pose_embeddings.%d.weight" % i].float().cpu()
         pk["pose_w"] = pe_w.to(device)
@@ -327,15 +348,17 @@ class ZeroAggregator(nn.Module):
         return pk
 
     def workspace(self, M, seq, device):
+        """Scratch for (tokens, sequence) -- cached, least-recently-used shapes beyond `max_workspaces` are dropped so a
+        long-lived process serving scenes of varying S / geometry does not accumulate one 2 GB scratch set per shape."""
         key = (M, seq, self.compute_dtype, str(device))
-        if key not in self._ws:
-            ws = Workspace(M, seq, self.compute_dtype, device)
-            for (m2, _, dt2, dv2), other in self._ws.items():
-                if m2 == M and dt2 == self.compute_dtype and dv2 == str(device):
-                    ws.share_from(other)
-                    break
-            self._ws[key] = ws
-        return self._ws[key]
+        ws = self._ws.pop(key, None)
+        if ws is None:
+            while len(self._ws) >= max(2, int(self.max_workspaces)):
+                self._ws.pop(next(iter(self._ws)))                  # dicts keep insertion order: first = least recently used
+            share = next((o for (m2, _, dt2, dv2), o in self._ws.items() if m2 == M and dt2 == self.compute_dtype and dv2 == str(device)), None)
+            ws = Workspace(M, seq, self.compute_dtype, device, share=share)
+        self._ws[key] = ws                                           # (re)insert as most recently used
+        return ws
 
     # ------------------------------------------------------------------
     def camera_tables(self, pk, extrinsics, intrinsics, camera_gt_index, B, S, hw, device):
@@ -354,7 +377,7 @@ class ZeroAggregator(nn.Module):
         intr = torch.index_select(intrinsics.detach().float().cpu(), 1, idx)
         enc = camera_math.pose_encoding(camera_math.normalize_extrinsics(ext), intr, hw)      # [B,Sc,9]
         Sc = len(camera_gt_index)
-        x = torch.zeros(B * Sc, 64)
+        x = torch.zeros(B * Sc, self.pose_k_pad)
         x[:, : self.pose_hidden_dim] = enc.reshape(B * Sc, -1)
         emb = ops.linear(x.to(device), pk["pose_w"], pk["pose_b"], torch.float32, out_f32=True)   # [B*Sc, G*1024]
         rows = (torch.arange(B).unsqueeze(1) * S + idx.unsqueeze(0)).reshape(-1).to(device)
@@ -382,9 +405,8 @@ class ZeroAggregator(nn.Module):
         stats = ops.depth_stats(d_sel, m_sel)
         cols = ops.im2col_depth(d_sel.view(B * n, H, W), m_sel.view(B * n, H, W), stats, n, self.compute_dtype)
         tok = ops.linear(cols, pk["depth_w"], pk["depth_b"], self.compute_dtype, out_f32=True)
-        for b in range(B):
-            for j, s in enumerate(depth_gt_index):
-                row[b * S + s] = b * n + j
+        sel = torch.as_tensor(list(depth_gt_index), dtype=torch.long)
+        row.view(B, S)[:, sel] = (torch.arange(B, dtype=torch.int32).unsqueeze(1) * n + torch.arange(n, dtype=torch.int32).unsqueeze(0))
         return tok, row.to(device)
 
     # ------------------------------------------------------------------
@@ -440,6 +462,6 @@ class ZeroAggregator(nn.Module):
             for i in range(self.depth):
                 buf = outs[i].view(T, 2 * C)
                 pk["frame"][i].forward(ws_f, x, buf[:, :C], inject=tables[i + 1], inj_period=P, **geo)
-                pk["global"][i].forward(ws_g, buf[:, :C], buf[:, C:], events=self.next_attention_events(), **geo)
+                pk["global"][i].forward(ws_g, buf[:, :C], buf[:, C:], events=self.next_attention_events(4.0 * B * (S * P) ** 2 * C), **geo)
                 x = buf[:, C:]
         return outs, self.patch_start_idx

@@ -35,14 +35,30 @@ def _digest():
         with open(f, "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
+
+
+def is_current():
+    """True when the in-tree .so was built from exactly the current sources / header / flags."""
+    stamp = OUT + ".stamp"
+    return os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read().strip() == _digest()
+
+
+def have_hipcc():
+    try:
+        c = _hipcc()
+    except RuntimeError:
+        return False
+    import shutil
+    return os.path.isabs(c) or shutil.which(c) is not None
 
 
 def build(force=False, verbose=True):
     """Compile every HIP translation unit for gfx950 and link the shared library."""
     stamp = OUT + ".stamp"
     dig = _digest()
-    if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+    if not force and is_current():
         return OUT
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")

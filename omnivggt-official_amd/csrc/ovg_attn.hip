@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256) void attn_kernel(ovg_attn_params p, int nqt, i
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
         store4<T>(dst + 16 * dt, o[qb][dt][0] * inv, o[qb][dt][1] * inv, o[qb][dt][2] * inv, o[qb][dt][3] * inv);
+      if (p.lse != nullptr && g == 0) p.lse[(int64_t)bh * p.nq_pad + q] = __builtin_amdgcn_logf(lt) + mrow[qb];
     }
   }
 }
@@ -316,6 +317,7 @@ extern "C" int ovg_flash_attn(const ovg_attn_params* p, void* stream) {
     if ((reinterpret_cast<uintptr_t>(s.k) | reinterpret_cast<uintptr_t>(s.vt)) & 15) return OVG_E_ARG;
   }
   if ((reinterpret_cast<uintptr_t>(p->q) | reinterpret_cast<uintptr_t>(p->out)) & 15) return OVG_E_ARG;
+  if (p->lse && (reinterpret_cast<uintptr_t>(p->lse) & 3)) return OVG_E_ARG;
   if (p->ldo % 4 || p->kv_heads < 0 || p->out_bh_stride < 0 || (p->out_bh_stride > 0 && (p->ldo < OVG_D || p->out_bh_stride % 4))) return OVG_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (p->dtype) {

@@ -98,10 +98,11 @@ OVG_DEV u32x4 pack2(const f32x4 a, const f32x4 b) {
 }
 
 // One pass over all key tiles of all segments for the wave's QB x 16 query rows; leaves the un-normalised
-// O^T in o and the row sums in lacc (every register of lacc[qb] holds the full sum of row q0 + 16 qb + lane&15).
+// O^T in o, the row sums in lacc (every register of lacc[qb] holds the full sum of row q0 + 16 qb + lane&15) and the
+// negated reference maximum in negm (P = exp2(s + negm)): log2 sum_k exp2(s) = log2(lacc) - negm.
 template <typename T, int QB, int WAVES, int SM>
 OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int bh, const int q0, const int total_tiles,
-                       f32x4 (&o)[QB][4], f32x4 (&lacc)[QB]) {
+                       f32x4 (&o)[QB][4], f32x4 (&lacc)[QB], f32x4 (&negm)[QB]) {
   constexpr int NT = 64 * WAVES;
   constexpr int RB = 128, KT_B = BC * RB, VT_B = OVG_D * RB, CPT = 512 / NT;
   const int tid = threadIdx.x;
@@ -120,7 +121,6 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
         qf[qb][kk] = *reinterpret_cast<const u32x4*>(qbase + (int64_t)q * RB + (4 * kk + g) * 16);
     }
   }
-  f32x4 negm[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     negm[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -321,11 +321,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn16_kernel(ovg_attn_params p
   const int nq = (int)p.nq;
   const int q0 = qt * BQ + wave * 16 * QB;
 
-  f32x4 o[QB][4], lacc[QB];
+  f32x4 o[QB][4], lacc[QB], negm[QB];
   if constexpr (MODE == 1) {
-    attn16::run_tiles<T, QB, WAVES, 0>(p, lds, bh, q0, total_tiles, o, lacc);
+    attn16::run_tiles<T, QB, WAVES, 0>(p, lds, bh, q0, total_tiles, o, lacc, negm);
   } else {
-    attn16::run_tiles<T, QB, WAVES, 2>(p, lds, bh, q0, total_tiles, o, lacc);
+    attn16::run_tiles<T, QB, WAVES, 2>(p, lds, bh, q0, total_tiles, o, lacc, negm);
     bool bad = MODE == 2;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn16_kernel(ovg_attn_params p
 #pragma unroll
         for (int r = 0; r < 4; ++r) bad = bad || attn16::nonfinite(o[qb][dt][r]);
     }
-    if (__syncthreads_or(bad ? 1 : 0)) attn16::run_tiles<T, QB, WAVES, 0>(p, lds, bh, q0, total_tiles, o, lacc);
+    if (__syncthreads_or(bad ? 1 : 0)) attn16::run_tiles<T, QB, WAVES, 0>(p, lds, bh, q0, total_tiles, o, lacc, negm);
   }
 
   const int bq = bh / OVG_H, hh = bh % OVG_H;
@@ -349,6 +349,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn16_kernel(ovg_attn_params p
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
         store4<T>(dst + 16 * dt, o[qb][dt][0] * inv, o[qb][dt][1] * inv, o[qb][dt][2] * inv, o[qb][dt][3] * inv);
+      if (p.lse != nullptr && g == 0) p.lse[(int64_t)bh * p.nq_pad + q] = __builtin_amdgcn_logf(lacc[qb][0]) - negm[qb][0];
     }
   }
 }

@@ -34,6 +34,7 @@ int run_prologue(const ovg_block_params* p, void* st, int part) {
   q.qk_norm = p->qk_norm; q.qn_w = p->w.qn_w; q.qn_b = p->w.qn_b; q.kn_w = p->w.kn_w; q.kn_b = p->w.kn_b; q.qk_eps = p->qk_eps;
   q.rope = p->rope; q.rope_cos = p->rope_cos; q.rope_sin = p->rope_sin; q.max_pos = p->max_pos;
   q.tokens_per_view = p->tokens_per_view; q.grid_w = p->grid_w; q.n_special = p->n_special;
+  q.tile = p->gemm_tile;
   q.q_scale = 0.125f * 1.4426950408889634f;   // head_dim^-0.5 * log2(e): attention uses exp2
   return ovg_qkv(&q, st);
 }
@@ -59,6 +60,7 @@ int run_epilogue(const ovg_block_params* p, void* st) {
   ovg_linear_params l{};
   l.x = p->ws_attn; l.ldx = OVG_C; l.w = p->w.proj_w; l.ldw = OVG_C; l.bias = p->w.proj_b;
   l.y = p->x_out; l.ldy = p->ld_out; l.M = p->M; l.N = OVG_C; l.K = OVG_C; l.dtype = p->dtype;
+  l.tile = p->gemm_tile;
   l.epilogue = OVG_EPI_RES; l.out_f32 = 1; l.res = p->x_in; l.ldres = p->ld_in; l.gamma = p->w.ls1;
   rc = ovg_linear(&l, st);
   if (rc) return rc;
@@ -73,7 +75,7 @@ int run_epilogue(const ovg_block_params* p, void* st) {
   ovg_linear_params f1{};
   f1.x = p->ws_xn; f1.ldx = OVG_C; f1.w = p->w.fc1_w; f1.ldw = OVG_C; f1.bias = p->w.fc1_b;
   f1.y = p->ws_hid; f1.ldy = OVG_HID; f1.M = p->M; f1.N = OVG_HID; f1.K = OVG_C; f1.dtype = p->dtype;
-  f1.epilogue = OVG_EPI_GELU; f1.out_f32 = 0;
+  f1.epilogue = OVG_EPI_GELU; f1.out_f32 = 0; f1.tile = p->gemm_tile;
   rc = ovg_linear(&f1, st);
   if (rc) return rc;
 
@@ -81,11 +83,26 @@ int run_epilogue(const ovg_block_params* p, void* st) {
   f2.x = p->ws_hid; f2.ldx = OVG_HID; f2.w = p->w.fc2_w; f2.ldw = OVG_HID; f2.bias = p->w.fc2_b;
   f2.y = p->x_out; f2.ldy = p->ld_out; f2.M = p->M; f2.N = OVG_C; f2.K = OVG_HID; f2.dtype = p->dtype;
   f2.epilogue = OVG_EPI_RES; f2.out_f32 = 1; f2.res = p->x_out; f2.ldres = p->ld_out; f2.gamma = p->w.ls2;
-  f2.inject = p->inject; f2.inj_period = p->inj_period;
+  f2.inject = p->inject; f2.inj_period = p->inj_period; f2.tile = p->gemm_tile;
   return ovg_linear(&f2, st);
 }
 
 }  // namespace
+
+extern "C" int ovg_block_workspace_bytes(const ovg_block_params* p, ovg_block_workspace* out) {
+  if (!p || !out || p->M <= 0 || p->seq <= 0 || p->M % p->seq || p->BH != (p->M / p->seq) * OVG_H) return OVG_E_ARG;
+  if (p->nq_pad < p->seq || p->nk_pad < p->seq || p->nk_pad % OVG_KV_TILE) return OVG_E_ARG;
+  if (p->dtype != OVG_BF16 && p->dtype != OVG_F16 && p->dtype != OVG_F32) return OVG_E_DTYPE;
+  const int64_t e = p->dtype == OVG_F32 ? 4 : 2;
+  out->xn = p->M * OVG_C * e;
+  out->attn = p->M * OVG_C * e;
+  out->hid = p->M * OVG_HID * e;
+  out->q = p->BH * p->nq_pad * OVG_D * e;
+  out->k = p->BH * p->nk_pad * OVG_D * e;
+  out->vt = p->BH * p->nk_pad * OVG_D * e;
+  out->total = out->xn + out->attn + out->hid + out->q + out->k + out->vt;
+  return OVG_OK;
+}
 
 extern "C" int ovg_block_attn_prologue(const ovg_block_params* p, void* stream) {
   int rc = check_block(p);

@@ -227,6 +227,77 @@ extern "C" int ovg_heads_to_tokens(const ovg_heads_to_tokens_params* p, void* st
   return OVG_OK;
 }
 
+// Exact combination of two attention results over disjoint key sets (header: ovg_attn_merge). One thread = 4
+// consecutive d of one (token, head); lse is head-major [16, n_pad] as written by the attention kernels.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_merge_kernel(ovg_attn_merge_params p, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c = (int)(idx & 255);                     // 4-element chunk of the 1024-wide row
+    const int64_t row = idx >> 8;
+    const int h = c >> 4;
+    const float la = p.lse_a[(int64_t)h * p.n_pad + row], lb = p.lse_b[(int64_t)h * p.n_pad + row];
+    const float m = fmaxf(la, lb);
+    const float wa = __builtin_amdgcn_exp2f(la - m), wb = __builtin_amdgcn_exp2f(lb - m);
+    const float inv = 1.0f / (wa + wb);
+    const T* a = static_cast<const T*>(p.a) + row * p.lda + c * 4;
+    const T* b = static_cast<const T*>(p.b) + row * p.ldb + c * 4;
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (wa * TT<T>::to_f32(a[i]) + wb * TT<T>::to_f32(b[i])) * inv;
+    store4<T>(static_cast<T*>(p.out) + row * p.ldo + c * 4, r[0], r[1], r[2], r[3]);
+  }
+}
+
+extern "C" int ovg_attn_merge(const ovg_attn_merge_params* p, void* stream) {
+  if (!p || !p->a || !p->b || !p->out || !p->lse_a || !p->lse_b || p->rows <= 0 || p->n_pad < p->rows) return OVG_E_ARG;
+  if (p->lda < OVG_C || p->ldb < OVG_C || p->ldo < OVG_C || (p->lda % 4) || (p->ldb % 4) || (p->ldo % 4)) return OVG_E_ARG;
+  if (!al16(p->a) || !al16(p->b) || !al16(p->out)) return OVG_E_ARG;
+  const int64_t total = p->rows * 256;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(grid_for(total, 256, 1 << 16)), block(256);
+  switch (p->dtype) {
+    case OVG_BF16: OVG_LAUNCH((attn_merge_kernel<bf16_t>), grid, block, 0, st, *p, total); break;
+    case OVG_F16: OVG_LAUNCH((attn_merge_kernel<f16_t>), grid, block, 0, st, *p, total); break;
+    case OVG_F32: OVG_LAUNCH((attn_merge_kernel<float>), grid, block, 0, st, *p, total); break;
+    default: return OVG_E_DTYPE;
+  }
+  OVG_CHECK_LAUNCH();
+  return OVG_OK;
+}
+
+// f32 [rows, k] -> dtype [rows, k_pad], zero beyond k (header: ovg_pack_weights); one thread = 8 output elements
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_kernel(ovg_pack_weights_params p, int64_t total, int cpr) {
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / cpr;
+    const int c0 = (int)(idx - row * cpr) * 8;
+    const float* src = p.src + row * p.lds;
+    T* dst = static_cast<T*>(p.dst) + row * p.ldd + c0;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (c0 + i) < p.k ? src[c0 + i] : 0.f;
+    store4<T>(dst, v[0], v[1], v[2], v[3]);
+    store4<T>(dst + 4, v[4], v[5], v[6], v[7]);
+  }
+}
+
+extern "C" int ovg_pack_weights(const ovg_pack_weights_params* p, void* stream) {
+  if (!p || !p->src || !p->dst || p->rows <= 0 || p->k <= 0 || p->k_pad < p->k || (p->k_pad % 8) || p->lds < p->k || p->ldd < p->k_pad) return OVG_E_ARG;
+  if (!al16(p->dst) || (p->ldd % 8)) return OVG_E_ARG;
+  const int cpr = (int)(p->k_pad / 8);
+  const int64_t total = p->rows * cpr;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(grid_for(total, 256, 1 << 16)), block(256);
+  switch (p->dtype) {
+    case OVG_BF16: OVG_LAUNCH((pack_weights_kernel<bf16_t>), grid, block, 0, st, *p, total, cpr); break;
+    case OVG_F16: OVG_LAUNCH((pack_weights_kernel<f16_t>), grid, block, 0, st, *p, total, cpr); break;
+    case OVG_F32: OVG_LAUNCH((pack_weights_kernel<float>), grid, block, 0, st, *p, total, cpr); break;
+    default: return OVG_E_DTYPE;
+  }
+  OVG_CHECK_LAUNCH();
+  return OVG_OK;
+}
+
 extern "C" int ovg_layernorm(const ovg_layernorm_params* p, void* stream) {
   if (!p || !p->x || !p->y || !p->weight || !p->bias || p->rows <= 0) return OVG_E_ARG;
   if (!al16(p->x) || !al16(p->y) || !al16(p->weight) || !al16(p->bias) || (p->ldx % 4) || (p->ldy % 4)) return OVG_E_ARG;

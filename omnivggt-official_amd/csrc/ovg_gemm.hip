@@ -136,86 +136,6 @@ OVG_DEV void gemm_mainloop(const T* __restrict__ X, int64_t ldx, const T* __rest
 }
 
 // ---------------------------------------------------------------------------
-// Main loop, LDS-DMA flavour: global -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no
-// ds_write), double-buffered, ONE barrier per k-step.  A wave-instruction deposits lane l's 16 bytes
-// at (wave-uniform LDS base) + 16*l, i.e. 8 consecutive 128-byte tile rows; the XOR swizzle is
-// therefore applied to the per-lane SOURCE address (global chunk = lds chunk ^ swizzle(row)) and
-// again on the fragment reads -- the destination stays linear.
-// ---------------------------------------------------------------------------
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-template <typename T, int ABL>   // ABL (diagnostic builds): 1 = no loads inside the loop, 2 = no MFMA
-OVG_DEV void gemm_mainloop_glds(const T* __restrict__ X, int64_t ldx, const T* __restrict__ W, int64_t ldw,
-                                int M, int N, int K, int m0, int n0, unsigned char* lds, f32x4 (&acc)[4][4]) {
-  constexpr int BKB = 128, TILE = 128 * BKB, BUF = 2 * TILE;     // bytes: one operand tile, one buffer (W|X)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave >> 1, wm = wave & 1;
-  const int g = lane >> 4, lr = lane & 15;
-
-  // wave w stages rows [32w, 32w+32) of each operand tile: 4 wave-instructions of 8 rows each
-  const unsigned char* xg[4];
-  const unsigned char* wg[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wave * 32 + i * 8 + (lane >> 3);
-    const int ch = (lane & 7) ^ ((row >> 1) & 7);                 // source chunk for linear LDS slot (lane&7)
-    int xr = m0 + row; xr = xr < M ? xr : M - 1;
-    int wr = n0 + row; wr = wr < N ? wr : N - 1;
-    xg[i] = reinterpret_cast<const unsigned char*>(X + (int64_t)xr * ldx) + ch * 16;
-    wg[i] = reinterpret_cast<const unsigned char*>(W + (int64_t)wr * ldw) + ch * 16;
-  }
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = (K * (int)sizeof(T)) / BKB;
-  auto stage = [&](int kt, int buf) {
-    unsigned char* wb = lds + buf * BUF + wave * 32 * BKB;        // wave-uniform destinations
-    unsigned char* xb = wb + TILE;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(wg[i] + (int64_t)kt * BKB), (lptr_t)(wb + i * 8 * BKB), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(xg[i] + (int64_t)kt * BKB), (lptr_t)(xb + i * 8 * BKB), 16, 0, 0);
-    }
-  };
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  const int sx = lr >> 1;
-  const int wrow = (wn * 64 + lr) * 128, xrow = TILE + (wm * 64 + lr) * 128;
-  int buf = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk && ABL != 1) stage(kt + 1, buf ^ 1);
-    const unsigned char* base = lds + buf * BUF;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int coff = ((kk * 4 + g) ^ sx) << 4;
-      u32x4 a[4], b[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        a[t] = *reinterpret_cast<const u32x4*>(base + wrow + t * 16 * 128 + coff);
-        b[t] = *reinterpret_cast<const u32x4*>(base + xrow + t * 16 * 128 + coff);
-      }
-      if constexpr (ABL != 2) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) TT<T>::mma(acc[nt][mt], a[nt], b[mt]);
-      } else {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) asm volatile("" :: "v"(a[t]), "v"(b[t]));
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    buf ^= 1;
-  }
-}
-
-// ---------------------------------------------------------------------------
 // Linear epilogues (STORE / GELU / RES / PATCH) on a wave's 64(n) x 16*MT(m) accumulator block:
 // acc[nt][mt] = C[n = n_w0 + 16nt + 4g + r][m = m_w0 + 16mt + (lane&15)]
 // ---------------------------------------------------------------------------
@@ -260,16 +180,15 @@ OVG_DEV void linear_epilogue(const ovg_linear_params& p, const f32x4 (&acc)[4][M
   }
 }
 
-template <typename T, int EPI, bool OUT_F32, int GLDS>   // GLDS: 0 register-staged, 1 LDS-DMA, 2/3 LDS-DMA ablations
+template <typename T, int EPI, bool OUT_F32>
 __global__ __launch_bounds__(256, 2) void linear_kernel(ovg_linear_params p, int ntiles_n) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[(GLDS ? 4 : 2) * 128 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128];
   const int M = (int)p.M, N = (int)p.N, K = (int)p.K;
   int tm, tn;
   tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + BM - 1) / BM, ntiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   f32x4 acc[4][4];
-  if constexpr (GLDS != 0) gemm_mainloop_glds<T, GLDS - 1>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds, acc);
-  else gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds, acc);
+  gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds, acc);
   const int wave = threadIdx.x >> 6;
   linear_epilogue<T, EPI, OUT_F32, 4>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64);
 }
@@ -372,17 +291,16 @@ OVG_DEV void qkv_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], co
   }
 }
 
-template <typename T, bool GLDS>
+template <typename T>
 __global__ __launch_bounds__(256, 2) void qkv_kernel(ovg_qkv_params p, int nt_begin, int nt_count) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[(GLDS ? 4 : 2) * 128 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128];
   constexpr int N = 3 * OVG_C, K = OVG_C;
   const int M = (int)p.M;
   int tm, tn;
   tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + BM - 1) / BM, nt_count, tm, tn);   // nt_count carries GM in its high half
   const int m0 = tm * BM, n0 = (nt_begin + tn) * BN;
   f32x4 acc[4][4];
-  if constexpr (GLDS) gemm_mainloop_glds<T, 0>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
-  else gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
+  gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
   const int wave = threadIdx.x >> 6;
   qkv_epilogue<T, 4>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64);
 }
@@ -390,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void qkv_kernel(ovg_qkv_params p, int nt_be
 #include "ovg_gemm256.h"
 
 // 256 x 256 ping-pong variants (16-bit modes): same epilogues on acc[4][8]
-template <typename T, int EPI, bool OUT_F32, int ABL = 0>
+template <typename T, int EPI, bool OUT_F32>
 __global__ __launch_bounds__(512) void linear256_kernel(ovg_linear_params p, int ntiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds256[];
   const int M = (int)p.M, N = (int)p.N, K = (int)p.K;
@@ -398,7 +316,7 @@ __global__ __launch_bounds__(512) void linear256_kernel(ovg_linear_params p, int
   tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + g256::BM2 - 1) / g256::BM2, ntiles_n, tm, tn);
   const int m0 = tm * g256::BM2, n0 = tn * g256::BN2;
   f32x4 acc[4][8];
-  g256::mainloop<T, ABL>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds256, acc);
+  g256::mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds256, acc);
   const int wave = threadIdx.x >> 6;
   linear_epilogue<T, EPI, OUT_F32, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64);
 }
@@ -422,46 +340,42 @@ int allow_big_lds(KernelT kernel) {     // once per kernel: opt in to > 64 KB of
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, g256::LDS_BYTES) == hipSuccess ? OVG_OK : OVG_E_LAUNCH;
 }
 
-int g_tile_group = 8;   // ovg_debug_set(0, v): tile-order group size (benchmarking knob)
-int g_tile_group256 = 4; // ovg_debug_set(2, v): same for the 256 x 256 kernels
-int g_mainloop = 0;     // ovg_debug_set(1, v): 0 = auto (128^2 register-staged or 256^2 ping-pong), 1 = LDS-DMA 128^2, 2/3 ablations,
-                        // 4 = force 256^2 ping-pong, 5/6 its ablations, 7 = force 128^2 register-staged
+// tile-order group sizes (m-tiles per group, tile_coords): measured in profiles/r01_gemm_tile_order_ab.txt / r01_gemm256_ab.txt
+constexpr int TILE_GROUP = 8, TILE_GROUP256 = 4;
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-
-
-template <typename T, int GLDS>
-int launch_linear_ml(const ovg_linear_params& p, hipStream_t st) {
+template <typename T>
+int launch_linear128(const ovg_linear_params& p, hipStream_t st) {
   const int mt = (int)((p.M + BM - 1) / BM), nt = (int)(p.N / BN);
   const dim3 grid(mt * nt), block(256);
-  const int ntg = nt | (g_tile_group << 16);
+  const int ntg = nt | (TILE_GROUP << 16);
   switch (p.epilogue) {
     case OVG_EPI_STORE:
-      if (p.out_f32) OVG_LAUNCH((linear_kernel<T, OVG_EPI_STORE, true, GLDS>), grid, block, 0, st, p, ntg);
-      else OVG_LAUNCH((linear_kernel<T, OVG_EPI_STORE, false, GLDS>), grid, block, 0, st, p, ntg);
+      if (p.out_f32) OVG_LAUNCH((linear_kernel<T, OVG_EPI_STORE, true>), grid, block, 0, st, p, ntg);
+      else OVG_LAUNCH((linear_kernel<T, OVG_EPI_STORE, false>), grid, block, 0, st, p, ntg);
       break;
     case OVG_EPI_GELU:
-      OVG_LAUNCH((linear_kernel<T, OVG_EPI_GELU, false, GLDS>), grid, block, 0, st, p, ntg);
+      OVG_LAUNCH((linear_kernel<T, OVG_EPI_GELU, false>), grid, block, 0, st, p, ntg);
       break;
     case OVG_EPI_RES:
-      OVG_LAUNCH((linear_kernel<T, OVG_EPI_RES, true, GLDS>), grid, block, 0, st, p, ntg);
+      OVG_LAUNCH((linear_kernel<T, OVG_EPI_RES, true>), grid, block, 0, st, p, ntg);
       break;
     case OVG_EPI_PATCH:
-      OVG_LAUNCH((linear_kernel<T, OVG_EPI_PATCH, true, GLDS>), grid, block, 0, st, p, ntg);
+      OVG_LAUNCH((linear_kernel<T, OVG_EPI_PATCH, true>), grid, block, 0, st, p, ntg);
       break;
     default: return OVG_E_ARG;
   }
   OVG_CHECK_LAUNCH();
   return OVG_OK;
 }
-template <typename T, int EPI, bool OUT_F32, int ABL = 0>
+template <typename T, int EPI, bool OUT_F32>
 int launch_linear256_one(const ovg_linear_params& p, hipStream_t st) {
-  static const int ok = allow_big_lds(linear256_kernel<T, EPI, OUT_F32, ABL>);
+  static const int ok = allow_big_lds(linear256_kernel<T, EPI, OUT_F32>);
   if (ok != OVG_OK) return ok;
   const int mt = (int)((p.M + g256::BM2 - 1) / g256::BM2), nt = (int)(p.N / g256::BN2);
-  const int ntg = nt | (g_tile_group256 << 16);
-  OVG_LAUNCH((linear256_kernel<T, EPI, OUT_F32, ABL>), dim3(mt * nt), dim3(512), g256::LDS_BYTES, st, p, ntg);
+  const int ntg = nt | (TILE_GROUP256 << 16);
+  OVG_LAUNCH((linear256_kernel<T, EPI, OUT_F32>), dim3(mt * nt), dim3(512), g256::LDS_BYTES, st, p, ntg);
   OVG_CHECK_LAUNCH();
   return OVG_OK;
 }
@@ -470,47 +384,38 @@ int launch_linear256(const ovg_linear_params& p, hipStream_t st) {
   switch (p.epilogue) {
     case OVG_EPI_STORE: return p.out_f32 ? launch_linear256_one<T, OVG_EPI_STORE, true>(p, st) : launch_linear256_one<T, OVG_EPI_STORE, false>(p, st);
     case OVG_EPI_GELU: return launch_linear256_one<T, OVG_EPI_GELU, false>(p, st);
-    case OVG_EPI_RES:
-      if (g_mainloop == 5) return launch_linear256_one<T, OVG_EPI_RES, true, 1>(p, st);   // diagnostic: no DMA in the loop
-      if (g_mainloop == 6) return launch_linear256_one<T, OVG_EPI_RES, true, 2>(p, st);   // diagnostic: no MFMAs
-      return launch_linear256_one<T, OVG_EPI_RES, true>(p, st);
+    case OVG_EPI_RES: return launch_linear256_one<T, OVG_EPI_RES, true>(p, st);
     case OVG_EPI_PATCH: return launch_linear256_one<T, OVG_EPI_PATCH, true>(p, st);
     default: return OVG_E_ARG;
   }
 }
-// Tile choice for the 16-bit modes (measured, tests/bench_kernels.py gemm --mainloops 0 4, profiles/r01_gemm256_ab.txt):
-// the 256 x 256 ping-pong loop wins by 9-14 % on QKV / fc1 / fc2 once its tiles fill the 256 CUs evenly, and
-// loses on the proj GEMM (K = 1024 with the f32 residual epilogue: one workgroup per CU cannot overlap that
-// epilogue with another workgroup's main loop) and on badly quantised grids (QKV at M = 10 992: 516 tiles =
-// 2.02 rounds). g_mainloop: 0 = this automatic choice, 1 = 128^2 LDS-DMA, 4 = force 256^2, 7 = force 128^2.
-bool use_256(int64_t M, int64_t N, int64_t K, bool light_epilogue_or_long_k) {
-  if (N % g256::BN2 != 0 || K % 32 != 0) return false;
-  if (g_mainloop >= 4 && g_mainloop <= 6) return true;
-  if (g_mainloop != 0) return false;
+// Tile choice for the 16-bit modes (measured, tests/bench_kernels.py gemm, profiles/r01_gemm256_ab.txt): the 256 x 256
+// ping-pong loop wins by 9-14 % on QKV / fc1 / fc2 once its tiles fill the 256 CUs evenly, and loses on the proj GEMM
+// (K = 1024 with the f32 residual epilogue: one workgroup per CU cannot overlap that epilogue with another workgroup's
+// main loop) and on badly quantised grids (QKV at M = 10 992: 516 tiles = 2.02 rounds).
+// Returns 1 = use 256^2, 0 = use 128^2, -1 = the caller forced a tile this shape / dtype cannot run.
+int choose_256(int tile, bool sixteen_bit, int64_t M, int64_t N, int64_t K, bool light_epilogue_or_long_k) {
+  const bool legal = sixteen_bit && N % g256::BN2 == 0 && K % 32 == 0;
+  if (tile == OVG_TILE_128) return 0;
+  if (tile == OVG_TILE_256) return legal ? 1 : -1;
+  if (tile != OVG_TILE_AUTO) return -1;
+  if (!legal) return 0;
   // in situ (bench.py, whole forward) the 256^2 kernels only pay off for long token slices: at M = 10 992 the
   // forward is 2 % faster with 128^2 everywhere, at M = 87 936 it is 2 % faster with this choice
-  if (!light_epilogue_or_long_k || M < 32768) return false;
+  if (!light_epilogue_or_long_k || M < 32768) return 0;
   const int64_t tiles = ((M + g256::BM2 - 1) / g256::BM2) * (N / g256::BN2);
   const int64_t rounds = (tiles + 255) / 256;
-  return tiles * 100 >= rounds * 256 * 80 || K >= 2048;   // >= 80 % of the last round's CUs busy
+  return (tiles * 100 >= rounds * 256 * 80 || K >= 2048) ? 1 : 0;   // >= 80 % of the last round's CUs busy
 }
 
 template <typename T>
 int launch_linear(const ovg_linear_params& p, hipStream_t st) {
+  const int big = choose_256(p.tile, sizeof(T) == 2, p.M, p.N, p.K, p.epilogue != OVG_EPI_RES || p.K >= 2048);
+  if (big < 0) return OVG_E_ARG;
   if constexpr (sizeof(T) == 2) {
-    if (use_256(p.M, p.N, p.K, p.epilogue != OVG_EPI_RES || p.K >= 2048)) return launch_linear256<T>(p, st);
+    if (big) return launch_linear256<T>(p, st);
   }
-  if constexpr (sizeof(T) == 2) {           // ablation builds exist for the bf16/f16 RES epilogue only
-    if ((g_mainloop == 2 || g_mainloop == 3) && p.epilogue == OVG_EPI_RES) {
-      const int mt = (int)((p.M + BM - 1) / BM), nt = (int)(p.N / BN);
-      const int ntg = nt | (g_tile_group << 16);
-      if (g_mainloop == 2) OVG_LAUNCH((linear_kernel<T, OVG_EPI_RES, true, 2>), dim3(mt * nt), dim3(256), 0, st, p, ntg);
-      else OVG_LAUNCH((linear_kernel<T, OVG_EPI_RES, true, 3>), dim3(mt * nt), dim3(256), 0, st, p, ntg);
-      OVG_CHECK_LAUNCH();
-      return OVG_OK;
-    }
-  }
-  return g_mainloop == 1 ? launch_linear_ml<T, 1>(p, st) : launch_linear_ml<T, 0>(p, st);
+  return launch_linear128<T>(p, st);
 }
 
 }  // namespace
@@ -544,6 +449,7 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
   if (!p || !p->x || !p->w || !p->bias || !p->q || !p->k || !p->vt) return OVG_E_ARG;
   if (p->M <= 0 || p->M > (1 << 30) || p->seq <= 0 || p->M % p->seq != 0) return OVG_E_ARG;
   if (p->nq_pad < p->seq || p->nk_pad < p->seq || p->nk_pad % OVG_KV_TILE != 0) return OVG_E_ARG;
+  if (p->dtype != OVG_BF16 && p->dtype != OVG_F16 && p->dtype != OVG_F32) return OVG_E_DTYPE;
   const int64_t esz = p->dtype == OVG_F32 ? 4 : 2;
   if ((p->ldx * esz) % 16 || !aligned16(p->x) || !aligned16(p->w) || !aligned16(p->bias) || !aligned16(p->q) || !aligned16(p->k) || !aligned16(p->vt)) return OVG_E_ARG;
   if (p->qk_norm && (!p->qn_w || !p->qn_b || !p->kn_w || !p->kn_b)) return OVG_E_ARG;
@@ -553,17 +459,15 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
     if (np <= 0 || (np - 1) / p->grid_w + 1 >= p->max_pos || p->grid_w >= p->max_pos) return OVG_E_ARG;
   }
   if (p->part < 0 || p->part > 2) return OVG_E_ARG;
-  const int q_tiles = OVG_C / BN, all_tiles = 3 * OVG_C / BN;
-  const int nt_begin = p->part == 1 ? q_tiles : 0;
-  const int nt_count = p->part == 0 ? all_tiles : (p->part == 1 ? all_tiles - q_tiles : q_tiles);
-  const dim3 grid((unsigned)(((p->M + BM - 1) / BM) * nt_count)), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (p->dtype != OVG_F32 && use_256(p->M, (p->part == 0 ? 3 : (p->part == 1 ? 2 : 1)) * OVG_C, OVG_C, true)) {
+  const int big = choose_256(p->tile, p->dtype != OVG_F32, p->M, (p->part == 0 ? 3 : (p->part == 1 ? 2 : 1)) * OVG_C, OVG_C, true);
+  if (big < 0) return OVG_E_ARG;
+  if (big) {
     const int q_t = OVG_C / g256::BN2, all_t = 3 * OVG_C / g256::BN2;
     const int ntb = p->part == 1 ? q_t : 0;
     const int ntc = p->part == 0 ? all_t : (p->part == 1 ? all_t - q_t : q_t);
     const dim3 grid2((unsigned)(((p->M + g256::BM2 - 1) / g256::BM2) * ntc));
-    const int ntg2 = ntc | (g_tile_group256 << 16);
+    const int ntg2 = ntc | (TILE_GROUP256 << 16);
     if (p->dtype == OVG_BF16) {
       static const int ok = allow_big_lds(qkv256_kernel<bf16_t>);
       if (ok != OVG_OK) return ok;
@@ -576,20 +480,16 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
     OVG_CHECK_LAUNCH();
     return OVG_OK;
   }
-  const int ntg = nt_count | (g_tile_group << 16);
+  const int q_tiles = OVG_C / BN, all_tiles = 3 * OVG_C / BN;
+  const int nt_begin = p->part == 1 ? q_tiles : 0;
+  const int nt_count = p->part == 0 ? all_tiles : (p->part == 1 ? all_tiles - q_tiles : q_tiles);
+  const dim3 grid((unsigned)(((p->M + BM - 1) / BM) * nt_count)), block(256);
+  const int ntg = nt_count | (TILE_GROUP << 16);
   switch (p->dtype) {
-    case OVG_BF16: if (g_mainloop == 1) OVG_LAUNCH((qkv_kernel<bf16_t, true>), grid, block, 0, st, *p, nt_begin, ntg); else OVG_LAUNCH((qkv_kernel<bf16_t, false>), grid, block, 0, st, *p, nt_begin, ntg); break;
-    case OVG_F16: if (g_mainloop == 1) OVG_LAUNCH((qkv_kernel<f16_t, true>), grid, block, 0, st, *p, nt_begin, ntg); else OVG_LAUNCH((qkv_kernel<f16_t, false>), grid, block, 0, st, *p, nt_begin, ntg); break;
-    case OVG_F32: if (g_mainloop == 1) OVG_LAUNCH((qkv_kernel<float, true>), grid, block, 0, st, *p, nt_begin, ntg); else OVG_LAUNCH((qkv_kernel<float, false>), grid, block, 0, st, *p, nt_begin, ntg); break;
-    default: return OVG_E_DTYPE;
+    case OVG_BF16: OVG_LAUNCH((qkv_kernel<bf16_t>), grid, block, 0, st, *p, nt_begin, ntg); break;
+    case OVG_F16: OVG_LAUNCH((qkv_kernel<f16_t>), grid, block, 0, st, *p, nt_begin, ntg); break;
+    default: OVG_LAUNCH((qkv_kernel<float>), grid, block, 0, st, *p, nt_begin, ntg); break;
   }
   OVG_CHECK_LAUNCH();
   return OVG_OK;
-}
-
-extern "C" int ovg_debug_set(int key, int value) {
-  if (key == 0 && value >= 0 && value < 256) { g_tile_group = value; return OVG_OK; }
-  if (key == 1 && value >= 0 && value <= 7) { g_mainloop = value; return OVG_OK; }
-  if (key == 2 && value >= 0 && value < 256) { g_tile_group256 = value; return OVG_OK; }
-  return OVG_E_ARG;
 }

@@ -42,16 +42,14 @@ OVG_DEV int swz64(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }   //
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int ABL = 0>
 OVG_DEV void wait_tiles_in_flight(int n) {     // leave at most n k-stages (4 DMA instructions each) outstanding
-  if (ABL == 1) return;
   if (n >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if (n == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // leaves acc[nt][mt] = C[n = n0 + 64 wn + 16 nt + 4g + r][m = m0 + 128 wm + 16 mt + (lane & 15)]
-template <typename T, int ABL = 0>   // ABL (diagnostic builds): 1 = no DMA inside the loop, 2 = no MFMAs
+template <typename T>
 OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict__ W, int64_t ldw,
                       int M, int N, int K, int m0, int n0, unsigned char* lds, f32x4 (&acc)[4][8]) {
   static_assert(sizeof(T) == 2, "16-bit operands");
@@ -99,17 +97,10 @@ OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict_
   };
   auto mfmas = [&]() {
     __builtin_amdgcn_s_setprio(1);
-    if constexpr (ABL != 2) {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) TT<T>::mma(acc[nt][mt], a[nt], b[mt]);
-    } else {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) asm volatile("" :: "v"(a[t]));
-#pragma unroll
-      for (int t = 0; t < 8; ++t) asm volatile("" :: "v"(b[t]));
-    }
+      for (int mt = 0; mt < 8; ++mt) TT<T>::mma(acc[nt][mt], a[nt], b[mt]);
     __builtin_amdgcn_s_setprio(0);
   };
   auto in_flight_after = [&](int t) {   // k-stages issued beyond tile t when the wave has staged up to tile min(t + 2, nk - 1)
@@ -125,14 +116,14 @@ OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict_
   if (wm == 0) {
     for (int t = 0; t < nk; ++t) {
       read_frags(t);                                 // L(t)
-      if (ABL != 1 && t + 3 < nk) stage(t + 3);
+      if (t + 3 < nk) stage(t + 3);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();                  // b(2t)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       mfmas();                                       // M(t)
       __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < nk) wait_tiles_in_flight<ABL>(in_flight_after(t + 1));   // w(t+1): stages issued so far reach t+3
+      if (t + 1 < nk) wait_tiles_in_flight(in_flight_after(t + 1));   // w(t+1): stages issued so far reach t+3
       __builtin_amdgcn_s_barrier();                  // b(2t+1)
     }
     __builtin_amdgcn_s_barrier();                    // pairs with group 1's last barrier
@@ -140,9 +131,9 @@ OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict_
     __builtin_amdgcn_s_barrier();                    // b0: one barrier behind group 0
     for (int t = 0; t < nk; ++t) {
       read_frags(t);                                 // L(t)
-      if (ABL != 1 && t + 3 < nk) stage(t + 3);
+      if (t + 3 < nk) stage(t + 3);
       __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < nk) wait_tiles_in_flight<ABL>(in_flight_after(t + 1));   // w(t+1)
+      if (t + 1 < nk) wait_tiles_in_flight(in_flight_after(t + 1));   // w(t+1)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                  // b(2t+1)
       __builtin_amdgcn_sched_barrier(0);

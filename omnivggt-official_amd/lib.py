@@ -14,7 +14,8 @@ OVG_BF16, OVG_F16, OVG_F32 = 0, 1, 2
 EPI_STORE, EPI_GELU, EPI_RES, EPI_PATCH = 0, 1, 2, 3
 OVG_MAX_SEG = 8
 KV_TILE = 64
-ABI_VERSION = 3
+ABI_VERSION = 4
+TILE_AUTO, TILE_128, TILE_256 = 0, 1, 2
 
 ERRORS = {0: "OVG_OK", -1: "OVG_E_ARG", -2: "OVG_E_DTYPE", -3: "OVG_E_LAUNCH", -4: "OVG_E_UNSUPPORTED"}
 
@@ -30,7 +31,7 @@ class LinearParams(C.Structure):
     _fields_ = [("x", vp), ("ldx", i64), ("w", vp), ("ldw", i64), ("bias", vp), ("y", vp), ("ldy", i64),
                 ("M", i64), ("N", i64), ("K", i64), ("dtype", i32), ("epilogue", i32), ("out_f32", i32),
                 ("res", vp), ("ldres", i64), ("gamma", vp), ("inject", vp), ("inj_period", i64),
-                ("table", vp), ("p0", i64), ("p1", i64), ("row_off", i64)]
+                ("table", vp), ("p0", i64), ("p1", i64), ("row_off", i64), ("tile", i32)]
 
 
 class QkvParams(C.Structure):
@@ -38,7 +39,7 @@ class QkvParams(C.Structure):
                 ("M", i64), ("seq", i64), ("nq_pad", i64), ("nk_pad", i64), ("dtype", i32),
                 ("qk_norm", i32), ("qn_w", vp), ("qn_b", vp), ("kn_w", vp), ("kn_b", vp), ("qk_eps", f32),
                 ("rope", i32), ("rope_cos", vp), ("rope_sin", vp), ("max_pos", i32),
-                ("tokens_per_view", i64), ("grid_w", i32), ("n_special", i32), ("q_scale", f32), ("part", i32)]
+                ("tokens_per_view", i64), ("grid_w", i32), ("n_special", i32), ("q_scale", f32), ("part", i32), ("tile", i32)]
 
 
 class KvSegment(C.Structure):
@@ -48,7 +49,12 @@ class KvSegment(C.Structure):
 class AttnParams(C.Structure):
     _fields_ = [("q", vp), ("nq", i64), ("nq_pad", i64), ("seg", KvSegment * OVG_MAX_SEG), ("nseg", i32),
                 ("out", vp), ("ldo", i64), ("BH", i64), ("dtype", i32), ("variant", i32),
-                ("kv_heads", i32), ("out_bh_stride", i64)]
+                ("kv_heads", i32), ("out_bh_stride", i64), ("lse", vp)]
+
+
+class AttnMergeParams(C.Structure):
+    _fields_ = [("a", vp), ("lda", i64), ("lse_a", vp), ("b", vp), ("ldb", i64), ("lse_b", vp),
+                ("out", vp), ("ldo", i64), ("rows", i64), ("n_pad", i64), ("dtype", i32)]
 
 
 class BlockWeights(C.Structure):
@@ -68,7 +74,15 @@ class BlockParams(C.Structure):
                 ("ws_xn", vp), ("ws_q", vp), ("ws_k", vp), ("ws_vt", vp), ("ws_attn", vp), ("ws_hid", vp),
                 ("extra", KvSegment * OVG_MAX_SEG), ("nseg_extra", i32), ("local_seg_index", i32),
                 ("attn_variant", i32), ("qkv_part", i32), ("ev_attn_start", vp), ("ev_attn_stop", vp),
-                ("skip_attention", i32)]
+                ("skip_attention", i32), ("gemm_tile", i32)]
+
+
+class BlockWorkspace(C.Structure):
+    _fields_ = [("xn", i64), ("q", i64), ("k", i64), ("vt", i64), ("attn", i64), ("hid", i64), ("total", i64)]
+
+
+class PackWeightsParams(C.Structure):
+    _fields_ = [("src", vp), ("lds", i64), ("dst", vp), ("ldd", i64), ("rows", i64), ("k", i64), ("k_pad", i64), ("dtype", i32)]
 
 
 class Im2colParams(C.Structure):
@@ -150,7 +164,9 @@ SYMBOLS = {
     "ovg_unproject": (i32, [C.POINTER(UnprojectParams), vp]),
     "ovg_heads_to_tokens": (i32, [C.POINTER(HeadsToTokensParams), vp]),
     "ovg_probe_mfma": (i32, [vp, vp, vp, i32, vp]),
-    "ovg_debug_set": (i32, [i32, i32]),
+    "ovg_attn_merge": (i32, [C.POINTER(AttnMergeParams), vp]),
+    "ovg_block_workspace_bytes": (i32, [C.POINTER(BlockParams), C.POINTER(BlockWorkspace)]),
+    "ovg_pack_weights": (i32, [C.POINTER(PackWeightsParams), vp]),
 }
 
 
@@ -162,15 +178,18 @@ _lib = None
 
 
 def load(build_if_missing=True):
-    """Load the shared library (building it in-tree with hipcc if it is absent)."""
+    """Load the shared library. A missing or STALE library (its build stamp differs from the digest of csrc/,
+    the header and the compiler flags) is rebuilt in-tree when hipcc is available, otherwise loading fails
+    loudly: kernels from an older source tree must never be validated or benchmarked by accident."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        if not build_if_missing:
-            raise OvgError("libomnivggt_hip.so is missing (run __graft_entry__.build()); there is no fallback path")
-        from .build import build
-        build()
+    from . import build as B
+    if not os.path.exists(LIB_PATH) or not B.is_current():
+        if not build_if_missing or not B.have_hipcc():
+            raise OvgError("libomnivggt_hip.so is %s (run __graft_entry__.build()); there is no fallback path"
+                           % ("missing" if not os.path.exists(LIB_PATH) else "stale: csrc/ changed since it was built"))
+        B.build()
     # torch bundles its own libamdhip64.so.7; it MUST be in the process before our library is
     # dlopen'ed, otherwise the loader maps /opt/rocm's copy for us and torch's copy for torch:
     # two HIP runtimes, and our launches on torch's streams fail (OVG_E_LAUNCH).
@@ -182,11 +201,6 @@ def load(build_if_missing=True):
         fn.argtypes = args
     if lib.ovg_abi_version() != ABI_VERSION:
         raise OvgError("ABI version mismatch: library %d, binding %d" % (lib.ovg_abi_version(), ABI_VERSION))
-    # benchmarking knobs (see ovg_debug_set in the header); never needed for correctness
-    if os.environ.get("OVG_GEMM_TILE_GROUP"):
-        lib.ovg_debug_set(0, int(os.environ["OVG_GEMM_TILE_GROUP"]))
-    if os.environ.get("OVG_GEMM_MAINLOOP"):
-        lib.ovg_debug_set(1, int(os.environ["OVG_GEMM_MAINLOOP"]))
     _lib = lib
     return lib
 

@@ -6,9 +6,10 @@
     model = model.to("cuda").eval()
     out = model(images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index)
 
-`compute_dtype` selects the aggregator arithmetic: torch.bfloat16 (default, throughput),
-torch.float16, or torch.float32 (parity mode: exact-f32 MFMA, matches the reference CPU
-path to ~1e-5 relative).  The camera head always runs in f32 PyTorch, like the reference (autocast
+`compute_dtype` selects the aggregator arithmetic: torch.float32 (the DEFAULT, like the reference, which runs
+fp32 end to end -- inference.py has no autocast, omnivggt.py:45 disables it around the heads: exact-f32 MFMA,
+matches the reference CPU path to <= 1e-4 relative), torch.bfloat16 or torch.float16 (throughput modes, an explicit
+opt-in: ~14x faster, tokens within the bf16-autocast twin's own error, profiles/r02_lowprec_parity.txt).  The camera head always runs in f32 PyTorch, like the reference (autocast
 disabled, omnivggt.py:45).  The two DPT heads run on the HIP kernels (heads_hip.py, 16-bit NHWC
 implicit-GEMM convolutions) in the 16-bit modes and as f32 PyTorch modules in the parity mode;
 `hip_heads=False` forces the PyTorch heads everywhere.
@@ -29,7 +30,7 @@ except Exception:  # pragma: no cover - optional
 
 class OmniVGGT(nn.Module, _HubMixin):
     def __init__(self, img_size=518, patch_size=14, embed_dim=1024, depth=24, dino_depth=24,
-                 compute_dtype=torch.bfloat16, dpt_layers=(4, 11, 17, 23), hip_heads=True):
+                 compute_dtype=torch.float32, dpt_layers=(4, 11, 17, 23), hip_heads=True):
         super().__init__()
         self.hip_heads = hip_heads
         self.aggregator = ZeroAggregator(img_size=img_size, patch_size=patch_size, embed_dim=embed_dim, depth=depth,

@@ -38,7 +38,7 @@ def layernorm(x, weight, bias, eps, dtype, out=None, out_f32=False):
 
 
 def linear(x, w, bias, dtype, epilogue=L.EPI_STORE, out=None, out_f32=False, res=None, gamma=None, inject=None,
-           inj_period=0, table=None, p0=0, p1=0, row_off=0, out_rows=None):
+           inj_period=0, table=None, p0=0, p1=0, row_off=0, out_rows=None, tile=L.TILE_AUTO):
     """y = epilogue(x @ w.T + bias); x [M,K], w [N,K] in dtype."""
     _chk_dev(x, w, bias, res, gamma, inject, table, out)
     M, K = x.shape
@@ -53,7 +53,7 @@ def linear(x, w, bias, dtype, epilogue=L.EPI_STORE, out=None, out_f32=False, res
     if res is not None:
         p.res, p.ldres = L.ptr(res), res.stride(0)
     p.gamma, p.inject, p.inj_period = L.ptr(gamma), L.ptr(inject), inj_period
-    p.table, p.p0, p.p1, p.row_off = L.ptr(table), p0, p1, row_off
+    p.table, p.p0, p.p1, p.row_off, p.tile = L.ptr(table), p0, p1, row_off, tile
     L.call("ovg_linear", p, _stream())
     return out
 
@@ -68,7 +68,7 @@ def alloc_qkv(BH, nq, nk, dtype, device):
 
 
 def qkv(x, w, bias, seq, dtype, q, k, vt, qk_norm=None, rope=None, tokens_per_view=1374, grid_w=37, n_special=5,
-        q_scale=0.125 * 1.4426950408889634, qk_eps=1e-5):
+        q_scale=0.125 * 1.4426950408889634, qk_eps=1e-5, part=0, tile=L.TILE_AUTO):
     """Fused QKV projection.  qk_norm = (qn_w, qn_b, kn_w, kn_b) or None; rope = (cos, sin) or None."""
     _chk_dev(x, w, bias, q, k, vt)
     p = L.QkvParams()
@@ -83,14 +83,16 @@ def qkv(x, w, bias, seq, dtype, q, k, vt, qk_norm=None, rope=None, tokens_per_vi
         p.rope = 1
         p.rope_cos, p.rope_sin, p.max_pos = L.ptr(rope[0]), L.ptr(rope[1]), rope[0].shape[0]
     p.tokens_per_view, p.grid_w, p.n_special, p.q_scale = tokens_per_view, grid_w, n_special, q_scale
+    p.part, p.tile = part, tile
     L.call("ovg_qkv", p, _stream())
 
 
-def flash_attn(q, segments, nq, dtype, out=None, variant=0, kv_heads=0, head_major=False):
+def flash_attn(q, segments, nq, dtype, out=None, variant=0, kv_heads=0, head_major=False, lse=None):
     """q [BH,nq_pad,64]; segments: list of (k [BHkv,nk_pad,64], vt [BHkv,64,nk_pad], nk).
     Returns out [B*nq, 1024] token-major, or with head_major=True out [BH, nq_pad, 64].
     kv_heads > 0: the segments hold kv_heads heads and batch entry bh attends to head bh % kv_heads
-    (head-parallel sharding: the BH entries are (source rank, head) pairs)."""
+    (head-parallel sharding: the BH entries are (source rank, head) pairs).
+    lse: optional f32 [BH, nq_pad] receiving log2(sum_k exp2(logit)) over the keys of this call (see attn_merge)."""
     _chk_dev(q)
     BH = q.shape[0]
     if out is None:
@@ -106,8 +108,48 @@ def flash_attn(q, segments, nq, dtype, out=None, variant=0, kv_heads=0, head_maj
         p.ldo, p.out_bh_stride = out.stride(1), out.stride(0)
     else:
         p.ldo = out.stride(0)
+    if lse is not None:
+        _chk_dev(lse)
+        if lse.dtype != torch.float32 or tuple(lse.shape) != (BH, q.shape[1]) or not lse.is_contiguous():
+            raise L.OvgError("lse must be a contiguous f32 [BH, nq_pad] tensor")
+        p.lse = L.ptr(lse)
     L.call("ovg_flash_attn", p, _stream())
     return out
+
+
+def attn_merge(a, lse_a, b, lse_b, dtype, out=None):
+    """Exact merge of two token-major attention results [n, 1024] over disjoint key sets (B = 1);
+    lse_a / lse_b f32 [16, n_pad] from flash_attn(..., lse=...). out may alias a or b."""
+    _chk_dev(a, b, lse_a, lse_b, out)
+    if out is None:
+        out = torch.empty_like(a)
+    p = L.AttnMergeParams(L.ptr(a), a.stride(0), L.ptr(lse_a), L.ptr(b), b.stride(0), L.ptr(lse_b), L.ptr(out), out.stride(0),
+                          a.shape[0], lse_a.shape[1], L.dtype_code(dtype))
+    L.call("ovg_attn_merge", p, _stream())
+    return out
+
+
+def pack_weights(src, dtype, k_pad=None):
+    """f32 [rows, k] (any trailing dims flattened) -> dtype [rows, k_pad] on the device, zero padded."""
+    _chk_dev(src)
+    s2 = src.detach().reshape(src.shape[0], -1).float().contiguous()
+    rows, k = s2.shape
+    k_pad = k if k_pad is None else k_pad
+    out = torch.empty(rows, k_pad, device=src.device, dtype=dtype)
+    p = L.PackWeightsParams(L.ptr(s2), s2.stride(0), L.ptr(out), out.stride(0), rows, k, k_pad, L.dtype_code(dtype))
+    L.call("ovg_pack_weights", p, _stream())
+    return out
+
+
+def block_workspace_bytes(M, seq, dtype):
+    """dict of scratch bytes an ovg_block_forward call with these shapes needs (host-only query)."""
+    p = L.BlockParams()
+    p.M, p.seq, p.BH = M, seq, (M // seq) * H
+    p.nq_pad = p.nk_pad = pad_to(seq, KV_TILE)
+    p.dtype = L.dtype_code(dtype)
+    ws = L.BlockWorkspace()
+    L.check(L.load().ovg_block_workspace_bytes(L.C.byref(p), L.C.byref(ws)), "ovg_block_workspace_bytes")
+    return {f: getattr(ws, f) for f, _ in L.BlockWorkspace._fields_}
 
 
 def heads_to_tokens(x, n, dtype, out=None):

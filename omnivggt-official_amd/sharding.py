@@ -3,30 +3,35 @@
 The reference has no parallelism at all; this is the one strategy the
 path admits (section 8e): everything except global attention is per-view, so rank r owns a
 contiguous range of views -- i.e. a contiguous slice of the (1, S*1374, C) global sequence
-(models/aggregator.py:317-318) -- and the only exchange is, per global block, an
-all-gather of the post-norm/post-RoPE K and of V^T.  On the 8-GPU full mesh an all-gather
-is 7 concurrent point-to-point writes of the local shard (per-link bound, ~45 MB per rank
-per layer at S=64), issued right after the K/V part of the QKV GEMM and overlapped with
-the Q part (async collective on RCCL's stream; the compute stream only waits before the
-attention kernel).  Attention then runs over `world` K/V^T segments in rank order (the
-online softmax makes the result independent of how keys are split).
+(models/aggregator.py:317-318) -- and the only data-path exchange sits inside the global blocks.
+Two exchange forms, both overlapped with compute (ViewSharding(mode=...)):
 
-Uneven S % world is handled by padding every rank's K/V^T buffer to the largest shard and
-passing the per-rank valid key count; the kernel masks each segment's tail.
+"allgather" -- the north star's collective: all-gather of the post-norm / post-RoPE K and of V^T.
+    LN1 + K/V part of the QKV GEMM -> async all-gather on RCCL's stream -> Q part of the QKV GEMM
+    -> attention launch A over the LOCAL keys only (needs nothing from the wire, writes O_a and the
+    per-row log-sum-exp) -> wait for the gather -> attention launch B over the world-1 REMOTE
+    segments (O_b, lse_b) -> ovg_attn_merge (exact: softmax over disjoint key sets combines through
+    the two log-sum-exps) -> proj + MLP. The gather hides behind the Q projection and launch A
+    (1/world of the attention work). Uneven S % world: every rank's K/V^T buffer is padded to the
+    largest shard, per-segment valid key counts mask the tails. Works for every dtype incl. f32.
 
-Head-parallel exchange (mode "heads", the default whenever the views split evenly and 16 % world == 0):
-the all-gather moves (world-1) x 45 MB INTO every rank per layer (~2 ms at the ~350 GB/s an 8-GPU xGMI
-all-gather sustains) against ~3.4 ms of attention, and nothing but the tiny Q projection can hide it.
-Instead each rank keeps all 16 heads of ITS tokens through the QKV GEMM, then three all-to-alls hand every
-rank the q, k, v^T of ALL tokens for ITS 16/world heads (a rank sends (world-1)/world of 67 MB, each peer
-pair exchanges 1/world of it over its own xGMI link), attention runs over 16 (source rank, head) batch
-entries with `world` K/V^T segments (`kv_heads`: entry bh reads head bh % (16/world)), and one all-to-all
-returns the head-major outputs: 4x fewer bytes per rank than the all-gather and every link busy at once.
-The q / k / v^T buffers are already head-major, so the send chunks are contiguous and the received K/V^T
-chunks are used in place as segments; only the returned O needs one head-major -> token-major copy.
+"heads" -- head-parallel all-to-all (the default whenever S % world == 0, 16 % world == 0, 16-bit):
+    the all-gather moves (world-1) x 45 MB INTO every rank per layer at S=64; the all-to-all form
+    moves 4x less: each rank runs the fused QKV GEMM for all 16 heads of ITS tokens, the q / k / v^T
+    of ALL tokens for ITS 16/world heads arrive by all-to-all (the buffers are head-major, so every
+    send chunk is contiguous and the received K / V^T chunks are used in place as `world` kernel
+    segments), attention runs over (source rank, head) batch entries (`kv_heads`), one all-to-all
+    returns the head-major outputs, ovg_heads_to_tokens restores the token-major layout.
+    Pipelined in HEAD GROUPS (2 groups when a rank owns >= 2 heads): all inbound exchanges are
+    issued up front on RCCL's stream; the compute stream waits for group 0 only, runs attention(0)
+    while group 1 is still arriving, returns O(0) under attention(1), ... -- about half of the
+    exchange time is hidden, the exposed part is one group's inbound + the last group's return.
 
-The numeric steps go through an *executor* (HipExecutor below); tests drive the same
-control flow over gloo on CPU with an oracle-backed executor (tests/test_sharding_gloo.py).
+The mode is a pure function of (S, world, dtype, requested mode), identical on every rank, so the
+ranks agree without talking; an impossible request raises BEFORE any collective is issued.
+
+The numeric steps go through an *executor* (HipExecutor below); tests drive the same control flow
+over gloo on CPU with an oracle-backed executor (tests/test_sharding_gloo.py).
 """
 import torch
 import torch.distributed as dist
@@ -47,12 +52,39 @@ def partition(n_views, world):
     return out
 
 
+def resolve_mode(requested, n_views, world, is_f32):
+    """Exchange form for this call; deterministic in its arguments (all ranks compute the same answer).
+    Raises ValueError for an explicit request the shapes / dtype cannot run."""
+    eligible = n_views % world == 0 and 16 % world == 0 and not is_f32
+    if requested == "heads":
+        if not eligible:
+            raise ValueError("head-parallel sharding needs S %% world == 0, 16 %% world == 0 and a 16-bit compute dtype "
+                             "(S=%d, world=%d, f32=%s)" % (n_views, world, is_f32))
+        return "heads"
+    if requested == "allgather":
+        return "allgather"
+    return "heads" if (eligible and world > 1) else "allgather"
+
+
+def head_groups(heads_per_rank):
+    """Pipeline groups of the heads form: [(first head, count)] inside a rank's head range."""
+    if heads_per_rank < 2:
+        return [(0, heads_per_rank)]
+    half = heads_per_rank // 2
+    return [(0, half), (half, heads_per_rank - half)]
+
+
 class HipExecutor:
-    """Numeric steps of the sharded forward on the gfx950 kernels."""
+    """Numeric steps of the sharded forward on the gfx950 kernels. Scratch and exchange buffers are cached per shape
+    (nothing is allocated inside the layer loop or per forward)."""
 
     def __init__(self, agg, device):
         self.agg, self.device = agg, device
         self.pk = agg.pack(device)
+        self._cache = {}
+
+    def _stream(self):
+        return torch.cuda.current_stream().cuda_stream
 
     def embed(self, inputs, view_slice):
         return self.agg.embed(self.pk, *inputs, view_slice=view_slice)
@@ -60,94 +92,128 @@ class HipExecutor:
     def new_outputs(self, n_local, P):
         return [torch.empty(1, n_local, P, 2 * C, device=self.device, dtype=torch.float32) for _ in range(self.agg.depth)]
 
-    def workspaces(self, n_local, max_local, P):
-        from .aggregator import Workspace
-        ws_f = self.agg.workspace(n_local * P, P, self.device)
-        # global workspace: K/V^T padded to the LARGEST shard so all ranks gather equal-sized buffers
-        ws_g = Workspace(n_local * P, n_local * P, self.agg.compute_dtype, self.device).share_from(ws_f)
-        pad = ops.pad_to(max_local * P, ops.KV_TILE)
-        ws_g.q, ws_g.k, ws_g.vt = ops.alloc_qkv(16, pad, pad, self.agg.compute_dtype, self.device)
-        return ws_f, ws_g
-
-    def gather_buffers(self, ws_g, world):
-        return (torch.empty((world,) + tuple(ws_g.k.shape), device=self.device, dtype=ws_g.k.dtype),
-                torch.empty((world,) + tuple(ws_g.vt.shape), device=self.device, dtype=ws_g.vt.dtype))
-
     def _geo(self):
         return dict(tokens_per_view=self.agg.tokens_per_view, grid_w=self.agg.grid_hw[1])
+
+    def _cached(self, key, make):
+        key = key + (self.agg.compute_dtype,)
+        if key not in self._cache:
+            if len(self._cache) >= 4:
+                self._cache.pop(next(iter(self._cache)))
+            self._cache[key] = make()
+        return self._cache[key]
+
+    # ---- K / V^T all-gather form ---------------------------------------------------------------------------
+    def workspaces(self, n_local, max_local, P):
+        """(frame workspace, global workspace): the global one shares the LN / attention / hidden scratch and pads
+        q / k / v^T to the LARGEST shard so all ranks gather equal-sized buffers; plus o_b / lse for the two-launch merge."""
+        from .aggregator import Workspace
+
+        def make():
+            dt = self.agg.compute_dtype
+            ws_f = self.agg.workspace(n_local * P, P, self.device)
+            pad = ops.pad_to(max_local * P, ops.KV_TILE)
+            ws_g = Workspace(n_local * P, n_local * P, dt, self.device, share=ws_f, kv_rows=pad)
+            ws_g.o_b = torch.empty(n_local * P, C, device=self.device, dtype=dt)
+            ws_g.lse_a = torch.empty(16, pad, device=self.device, dtype=torch.float32)
+            ws_g.lse_b = torch.empty(16, pad, device=self.device, dtype=torch.float32)
+            return ws_f, ws_g
+        return self._cached(("ag", n_local, max_local, P), make)
+
+    def gather_buffers(self, ws_g, world):
+        return self._cached(("agbuf", tuple(ws_g.k.shape), world), lambda: (
+            torch.empty((world,) + tuple(ws_g.k.shape), device=self.device, dtype=ws_g.k.dtype),
+            torch.empty((world,) + tuple(ws_g.vt.shape), device=self.device, dtype=ws_g.vt.dtype)))
 
     def frame_block(self, i, ws, x_in, x_out, inject, P):
         self.pk["frame"][i].forward(ws, x_in, x_out, inject=inject, inj_period=P, **self._geo())
 
-    def global_kv(self, i, ws, x_in, x_out):
+    def _prologue(self, i, ws, x_in, x_out, part):
         from . import lib as L
         p = self.pk["global"][i].params(ws, x_in, x_out, **self._geo())
-        p.qkv_part = 1
-        L.call("ovg_block_attn_prologue", p, torch.cuda.current_stream().cuda_stream)
+        p.qkv_part = part
+        L.call("ovg_block_attn_prologue", p, self._stream())
+
+    def global_kv(self, i, ws, x_in, x_out):
+        self._prologue(i, ws, x_in, x_out, 1)
         return ws.k, ws.vt
 
     def global_q(self, i, ws, x_in, x_out):
-        from . import lib as L
-        p = self.pk["global"][i].params(ws, x_in, x_out, **self._geo())
-        p.qkv_part = 2
-        L.call("ovg_block_attn_prologue", p, torch.cuda.current_stream().cuda_stream)
+        self._prologue(i, ws, x_in, x_out, 2)
 
-    def global_rest(self, i, ws, x_in, x_out, kg, vg, counts, rank):
-        from . import lib as L
-        p = self.pk["global"][i].params(ws, x_in, x_out, **self._geo())
-        e = 0
-        for r, nk in enumerate(counts):
-            if r == rank:
-                continue
-            p.extra[e].k, p.extra[e].vt, p.extra[e].nk, p.extra[e].nk_pad = kg[r].data_ptr(), vg[r].data_ptr(), nk, kg.shape[2]
-            e += 1
-        p.nseg_extra, p.local_seg_index = e, rank
-        ev = self.agg.next_attention_events()
-        if ev is not None:
-            p.ev_attn_start, p.ev_attn_stop = ev[0].cuda_event, ev[1].cuda_event
-        L.call("ovg_block_attn_epilogue", p, torch.cuda.current_stream().cuda_stream)
-
-
-    # ---- head-parallel (all-to-all) global attention -----------------------------------------------------
-    def heads_workspaces(self, n_local, P):
-        """(frame workspace, global workspace with q/k/vt [16, pad, 64] of the LOCAL tokens, exchange buffers)."""
-        ws_f = self.agg.workspace(n_local * P, P, self.device)
-        ws_g = self.agg.workspace(n_local * P, n_local * P, self.device)
-        ex = {"q": torch.empty_like(ws_g.q), "k": torch.empty_like(ws_g.k), "vt": torch.empty_like(ws_g.vt),
-              "o": torch.empty_like(ws_g.q), "o_back": torch.empty_like(ws_g.q)}
-        return ws_f, ws_g, ex
-
-    def global_qkv(self, i, ws, x_in, x_out):
-        from . import lib as L
-        p = self.pk["global"][i].params(ws, x_in, x_out, **self._geo())
-        p.qkv_part = 0
-        L.call("ovg_block_attn_prologue", p, torch.cuda.current_stream().cuda_stream)
-        return ws.q, ws.k, ws.vt
-
-    def head_attention(self, qr, kr, vr, out, n, world):
-        """qr / kr [world, 16/world, pad, 64], vr [world, 16/world, 64, pad] as received (flattened on dim 0)."""
-        hpr = qr.shape[0] // world
-        segs = [(kr[r * hpr:(r + 1) * hpr], vr[r * hpr:(r + 1) * hpr], n) for r in range(world)]
-        ev = self.agg.next_attention_events()
+    def _attention(self, q, segs, n, out, lse=None, kv_heads=0, head_major=False):
+        """One flash-attention launch, timed with a HIP event pair when bench.py asked for it."""
+        nk = sum(s[2] for s in segs)
+        ev = self.agg.next_attention_events(4.0 * q.shape[0] * n * nk * 64)
         if ev is not None:
             ev[0].record()
-        ops.flash_attn(qr, segs, n, self.agg.compute_dtype, out=out, variant=self.agg.attn_variant, kv_heads=hpr, head_major=True)
+        ops.flash_attn(q, segs, n, self.agg.compute_dtype, out=out, variant=self.agg.attn_variant, kv_heads=kv_heads,
+                       head_major=head_major, lse=lse)
         if ev is not None:
             ev[1].record()
         return out
+
+    def attend_local(self, i, ws, n, want_lse):
+        """Launch A: this rank's queries against its OWN keys (nothing from the wire) -> ws.attn (+ lse_a)."""
+        self._attention(ws.q, [(ws.k, ws.vt, n)], n, ws.attn, lse=ws.lse_a if want_lse else None)
+
+    def attend_remote(self, i, ws, kg, vg, counts, rank, n):
+        """Launch B: the same queries against the gathered segments of the other ranks -> ws.o_b, lse_b."""
+        segs = [(kg[r], vg[r], c) for r, c in enumerate(counts) if r != rank]
+        self._attention(ws.q, segs, n, ws.o_b, lse=ws.lse_b)
+
+    def merge_finish(self, i, ws, x_in, x_out, n, merged):
+        """Combine launches A and B (if there was a B) into ws.attn, then proj + MLP (epilogue without attention)."""
+        from . import lib as L
+        if merged:
+            ops.attn_merge(ws.attn, ws.lse_a, ws.o_b, ws.lse_b, self.agg.compute_dtype, out=ws.attn)
+        p = self.pk["global"][i].params(ws, x_in, x_out, **self._geo())
+        p.skip_attention = 1
+        L.call("ovg_block_attn_epilogue", p, self._stream())
+
+    # ---- head-parallel (all-to-all) form -------------------------------------------------------------------
+    def heads_workspaces(self, n_local, P, world):
+        """(frame workspace, global workspace with q/k/vt [16, pad, 64] of the LOCAL tokens, exchange buffers).
+        Exchange buffers per head group g of `gs` heads: inbound q / k [world, gs, pad, 64], vt [world, gs, 64, pad]
+        (chunk s = from source rank s), the attention output o (same shape as q) and the returned o_back [16, pad, 64]
+        in global head order."""
+        def make():
+            ws_f = self.agg.workspace(n_local * P, P, self.device)
+            ws_g = self.agg.workspace(n_local * P, n_local * P, self.device)
+            pad = ws_g.q.shape[1]
+            dt, dev = ws_g.q.dtype, self.device
+            groups = []
+            for h0, gs in head_groups(16 // world):
+                groups.append({"h0": h0, "gs": gs,
+                               "q": torch.zeros(world, gs, pad, 64, device=dev, dtype=dt), "k": torch.zeros(world, gs, pad, 64, device=dev, dtype=dt),
+                               "vt": torch.zeros(world, gs, 64, pad, device=dev, dtype=dt), "o": torch.zeros(world, gs, pad, 64, device=dev, dtype=dt)})
+            return ws_f, ws_g, {"groups": groups, "o_back": torch.zeros_like(ws_g.q)}
+        return self._cached(("heads", n_local, P, world), make)
+
+    def global_qkv(self, i, ws, x_in, x_out):
+        self._prologue(i, ws, x_in, x_out, 0)
+        return ws.q, ws.k, ws.vt
+
+    def head_attention(self, qr, kr, vr, out, n, world):
+        """qr / kr [world, gs, pad, 64], vr [world, gs, 64, pad] as received; batch entry (s, g) attends to head g of
+        every source's K / V^T chunk (kv_heads = gs, `world` segments); out like qr (head-major)."""
+        gs = qr.shape[1]
+        segs = [(kr[r], vr[r], n) for r in range(world)]
+        return self._attention(qr.flatten(0, 1), segs, n, out.flatten(0, 1), kv_heads=gs, head_major=True)
 
     def global_finish(self, i, ws, x_in, x_out, o_back, n):
         from . import lib as L
         ops.heads_to_tokens(o_back, n, self.agg.compute_dtype, out=ws.attn)
         p = self.pk["global"][i].params(ws, x_in, x_out, **self._geo())
         p.skip_attention = 1
-        L.call("ovg_block_attn_epilogue", p, torch.cuda.current_stream().cuda_stream)
+        L.call("ovg_block_attn_epilogue", p, self._stream())
 
 
 class ViewSharding:
     """Attach to a ZeroAggregator (`agg.shard = ViewSharding(group)`) to run it view-sharded.
-    mode: "auto" (head-parallel all-to-all when the views split evenly and 16 % world == 0, else K/V all-gather),
-    "heads" or "allgather"."""
+    mode: "auto" (head-parallel all-to-all when the views split evenly, 16 % world == 0 and the dtype is 16-bit, else
+    K/V all-gather), "heads" or "allgather".  skip_comm (bench.py only): issue no collective at all -- the step then
+    runs the same kernels on whatever the exchange buffers hold, which times the compute of a sharded step alone."""
 
     def __init__(self, group=None, executor_factory=None, gather_output=False, mode="auto"):
         if mode not in ("auto", "heads", "allgather"):
@@ -161,6 +227,16 @@ class ViewSharding:
         self.executor_factory = executor_factory or (lambda agg, device: HipExecutor(agg, device))
         self.gather_output = gather_output
         self.last_partition = None
+        self.last_mode = None
+        self.skip_comm = False
+        self._executors = {}
+
+    def executor(self, agg, device):
+        key = (id(agg), str(device), getattr(agg, "compute_dtype", None), id(getattr(agg, "_packed", None)))
+        if key not in self._executors:
+            self._executors.clear()                      # a re-pack / dtype change invalidates the old executor's buffers
+            self._executors[key] = self.executor_factory(agg, device)
+        return self._executors[key]
 
     # ---- collectives: RCCL on device tensors; with a host backend (gloo) device tensors are staged through the
     #      host, so the same control flow also runs where RCCL cannot (tests, several ranks sharing one GPU) -------
@@ -168,63 +244,66 @@ class ViewSharding:
         def wait(self):
             return None
 
-    def _staged(self, t):
-        return t.is_cuda and dist.get_backend(self.group) != "nccl"
+    def _nccl(self):
+        return dist.get_backend(self.group) == "nccl"
 
     def _all_gather(self, out, inp, async_op=False):
-        if self._staged(inp):
+        if self.skip_comm:
+            return self._Done()
+        if not self._nccl():
             tmp = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_gather_into_tensor(tmp, inp.cpu(), group=self.group)
+            dist.all_gather_into_tensor(tmp, inp.cpu().contiguous(), group=self.group)
             out.copy_(tmp)
             return self._Done()
         w = dist.all_gather_into_tensor(out, inp, group=self.group, async_op=async_op)
         return w if async_op else self._Done()
 
-    def _all_to_all(self, out, inp):
-        if self._staged(inp):
-            tmp = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_to_all_single(tmp, inp.cpu(), group=self.group)
-            out.copy_(tmp)
-        else:
-            dist.all_to_all_single(out, inp, group=self.group)
+    def _all_to_all_chunks(self, outs, ins, async_op=False):
+        """List-form all-to-all: ins[r] (contiguous) goes to rank r, outs[s] receives rank s's chunk for this rank.
+        RCCL: one grouped send/recv (no staging copy); host backends: stacked all_to_all_single through the host."""
+        if self.skip_comm:
+            return self._Done()
+        if not self._nccl():
+            send = torch.stack([t.cpu() for t in ins]).contiguous()
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send, group=self.group)
+            for r, o in enumerate(outs):
+                o.copy_(recv[r])
+            return self._Done()
+        w = dist.all_to_all(outs, ins, group=self.group, async_op=async_op)
+        return w if async_op else self._Done()
 
     def _all_reduce_max(self, t):
-        if self._staged(t):
+        if not self._nccl() and t.is_cuda:
             tmp = t.cpu()
             dist.all_reduce(tmp, op=dist.ReduceOp.MAX, group=self.group)
             t.copy_(tmp)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
 
-    def choose_mode(self, run, n_views, tol=5e-2):
-        """Self-check for mode "auto": `run()` must execute one sharded forward and return a tensor of it (e.g. the
-        last layer). Runs the K/V all-gather form and the head-parallel all-to-all form once each, compares them, lets
-        all ranks agree (MAX all-reduce of a failure flag) and pins `self.mode` to the all-to-all form only if it ran
-        and matched. Returns a small report dict."""
-        report = {}
-        if n_views % self.world != 0 or 16 % self.world != 0:
-            self.mode = "allgather"
-            report["exchange"] = "K/V all-gather"
-            return report
+    def compare_modes(self, run, n_views, is_f32=False):
+        """Diagnostic used by bench.py: run one sharded forward in each exchange form the shapes admit and report the
+        max-rel difference between them (MAX over ranks). `run()` must execute one forward and return a tensor of it.
+        No exception handling around collectives: a failing RCCL call must crash the job, not desynchronise it."""
+        saved = self.mode
+        report = {"modes": ["allgather"]}
         self.mode = "allgather"
         ref = run().float().clone()
-        self.mode = "heads"
-        bad = torch.zeros(1, device=ref.device)
-        err = float("nan")
         try:
-            got = run().float()
-            err = float((got - ref).abs().max() / ref.abs().max().clamp(min=1e-30))
-            bad[0] = 0.0 if err < tol else 1.0
-        except Exception as e:                             # only on a broken collective / kernel
-            bad[0] = 1.0
-            report["error"] = repr(e)[:200]
-        self._all_reduce_max(bad)
-        if float(bad.item()) > 0:
-            self.mode = "allgather"
-        report["selfcheck_max_rel_vs_allgather"] = err
-        report["exchange"] = "K/V all-gather" if self.mode == "allgather" else "head-parallel all-to-all"
+            resolve_mode("heads", n_views, self.world, is_f32)
+        except ValueError:
+            self.mode = saved
+            return report
+        self.mode = "heads"
+        got = run().float()
+        err = torch.tensor([float((got - ref).abs().max() / ref.abs().max().clamp(min=1e-30))], device=ref.device)
+        self._all_reduce_max(err)
+        self.mode = saved
+        report["modes"].append("heads")
+        report["max_rel_heads_vs_allgather"] = float(err.item())
         return report
 
+    # ---------------------------------------------------------------------------------------------------------
     def forward(self, agg, images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index):
         B, S = images.shape[:2]
         if B != 1:
@@ -233,68 +312,118 @@ class ViewSharding:
             raise ValueError("fewer views (%d) than ranks (%d)" % (S, self.world))
         if self.world > ops.L.OVG_MAX_SEG:
             raise ValueError("at most %d ranks per attention call" % ops.L.OVG_MAX_SEG)
+        # every check that can fail happens here, identically on every rank, BEFORE the first collective
+        mode = resolve_mode(self.mode, S, self.world, getattr(agg, "compute_dtype", None) == torch.float32)
+        self.last_mode = mode
         agg.set_geometry(images.shape[-2], images.shape[-1])
         P = agg.tokens_per_view
         parts = partition(S, self.world)
         self.last_partition = parts
         lo, hi = parts[self.rank]
-        n_local, max_local = hi - lo, max(h - l for l, h in parts)
-        counts = [(h - l) * P for l, h in parts]
-        ex = self.executor_factory(agg, images.device)
-        even = S % self.world == 0 and 16 % self.world == 0
-        if self.mode == "heads" and not even:
-            raise ValueError("head-parallel sharding needs S % world == 0 and 16 % world == 0")
-        f32_path = getattr(agg, "compute_dtype", None) == torch.float32     # heads_to_tokens is 16-bit only
-        if self.mode == "heads" or (self.mode == "auto" and even and self.world > 1 and not f32_path):
-            return self._forward_heads(agg, ex, images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index,
-                                       parts, lo, hi, P)
-
+        ex = self.executor(agg, images.device)
+        inputs = (images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index)
         with torch.no_grad():
-            tokens0, tables = ex.embed((images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index), (lo, hi))
-            ws_f, ws_g = ex.workspaces(n_local, max_local, P)
-            kg, vg = ex.gather_buffers(ws_g, self.world)
-            outs = ex.new_outputs(n_local, P)
-            x = tokens0
-            for i in range(agg.depth):
-                buf = outs[i].view(n_local * P, 2 * C)
-                ex.frame_block(i, ws_f, x, buf[:, :C], tables[i + 1][lo:hi].contiguous(), P)
-                k_loc, vt_loc = ex.global_kv(i, ws_g, buf[:, :C], buf[:, C:])
+            if mode == "heads":
+                outs = self._forward_heads(agg, ex, inputs, lo, hi, P)
+            else:
+                outs = self._forward_allgather(agg, ex, inputs, parts, lo, hi, P)
+            if self.gather_output:
+                outs = [self.gather_views(o, parts) for o in outs]
+        return outs, agg.patch_start_idx
+
+    def _forward_allgather(self, agg, ex, inputs, parts, lo, hi, P):
+        n_local, max_local = hi - lo, max(h - l for l, h in parts)
+        n = n_local * P
+        counts = [(h - l) * P for l, h in parts]
+        remote = self.world > 1
+        tokens0, tables = ex.embed(inputs, (lo, hi))
+        ws_f, ws_g = ex.workspaces(n_local, max_local, P)
+        kg, vg = ex.gather_buffers(ws_g, self.world)
+        outs = ex.new_outputs(n_local, P)
+        x = tokens0
+        for i in range(agg.depth):
+            buf = outs[i].view(n, 2 * C)
+            ex.frame_block(i, ws_f, x, buf[:, :C], tables[i + 1][lo:hi].contiguous(), P)
+            k_loc, vt_loc = ex.global_kv(i, ws_g, buf[:, :C], buf[:, C:])
+            if remote:
                 wk = self._all_gather(kg.flatten(0, 1), k_loc, async_op=True)
                 wv = self._all_gather(vg.flatten(0, 1), vt_loc, async_op=True)
-                ex.global_q(i, ws_g, buf[:, :C], buf[:, C:])          # overlaps the all-gather
+            ex.global_q(i, ws_g, buf[:, :C], buf[:, C:])              # overlaps the all-gather
+            ex.attend_local(i, ws_g, n, want_lse=remote)              # so does the attention over the local keys
+            if remote:
                 wk.wait()
                 wv.wait()
-                ex.global_rest(i, ws_g, buf[:, :C], buf[:, C:], kg, vg, counts, self.rank)
-                x = buf[:, C:]
-            if self.gather_output:
-                outs = [self.gather_views(o, parts) for o in outs]
-        return outs, agg.patch_start_idx
+                ex.attend_remote(i, ws_g, kg, vg, counts, self.rank, n)
+            ex.merge_finish(i, ws_g, buf[:, :C], buf[:, C:], n, merged=remote)
+            x = buf[:, C:]
+        return outs
 
-    def _forward_heads(self, agg, ex, images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index, parts, lo, hi, P):
-        """Head-parallel global attention: q / k / v^T all-to-all -> attention over this rank's heads for ALL
-        tokens -> all-to-all of the head-major outputs back to the token owners (module docstring)."""
+    def _forward_heads(self, agg, ex, inputs, lo, hi, P):
+        """Head-parallel global attention, pipelined in head groups (module docstring)."""
         n_local = hi - lo
         n = n_local * P
-        a2a = self._all_to_all
-        with torch.no_grad():
-            tokens0, tables = ex.embed((images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index), (lo, hi))
-            ws_f, ws_g, xb = ex.heads_workspaces(n_local, P)
-            outs = ex.new_outputs(n_local, P)
-            x = tokens0
-            for i in range(agg.depth):
-                buf = outs[i].view(n, 2 * C)
-                ex.frame_block(i, ws_f, x, buf[:, :C], tables[i + 1][lo:hi].contiguous(), P)
-                q, k, vt = ex.global_qkv(i, ws_g, buf[:, :C], buf[:, C:])
-                a2a(xb["q"], q)
-                a2a(xb["k"], k)
-                a2a(xb["vt"], vt)
-                ex.head_attention(xb["q"], xb["k"], xb["vt"], xb["o"], n, self.world)
-                a2a(xb["o_back"], xb["o"])
-                ex.global_finish(i, ws_g, buf[:, :C], buf[:, C:], xb["o_back"], n)
-                x = buf[:, C:]
-            if self.gather_output:
-                outs = [self.gather_views(o, parts) for o in outs]
-        return outs, agg.patch_start_idx
+        W = self.world
+        hpr = 16 // W
+        tokens0, tables = ex.embed(inputs, (lo, hi))
+        ws_f, ws_g, xb = ex.heads_workspaces(n_local, P, W)
+        groups, o_back = xb["groups"], xb["o_back"]
+        outs = ex.new_outputs(n_local, P)
+        x = tokens0
+        for i in range(agg.depth):
+            buf = outs[i].view(n, 2 * C)
+            ex.frame_block(i, ws_f, x, buf[:, :C], tables[i + 1][lo:hi].contiguous(), P)
+            q, k, vt = ex.global_qkv(i, ws_g, buf[:, :C], buf[:, C:])
+            inbound = []
+            for g in groups:                                          # all inbound exchanges queue up on RCCL's stream
+                sl = [slice(r * hpr + g["h0"], r * hpr + g["h0"] + g["gs"]) for r in range(W)]
+                inbound.append([self._all_to_all_chunks(list(g["q"].unbind(0)), [q[s] for s in sl], async_op=True),
+                                self._all_to_all_chunks(list(g["k"].unbind(0)), [k[s] for s in sl], async_op=True),
+                                self._all_to_all_chunks(list(g["vt"].unbind(0)), [vt[s] for s in sl], async_op=True)])
+            returns = []
+            for g, works in zip(groups, inbound):
+                for w in works:
+                    w.wait()                                          # compute stream waits for THIS group only
+                ex.head_attention(g["q"], g["k"], g["vt"], g["o"], n, W)
+                back = [o_back[r * hpr + g["h0"]: r * hpr + g["h0"] + g["gs"]] for r in range(W)]
+                returns.append(self._all_to_all_chunks(back, list(g["o"].unbind(0)), async_op=True))   # under the next group's attention
+            for w in returns:
+                w.wait()
+            ex.global_finish(i, ws_g, buf[:, :C], buf[:, C:], o_back, n)
+            x = buf[:, C:]
+        return outs
+
+    def exchange_only(self, agg, S, device, mode=None, layers=24):
+        """bench.py: issue ONLY the collectives of `layers` global blocks (same sizes, same order, nothing to hide
+        behind) on the cached buffers -- the un-overlapped cost of the exchange."""
+        mode = resolve_mode(mode or self.mode, S, self.world, getattr(agg, "compute_dtype", None) == torch.float32)
+        P = agg.tokens_per_view
+        parts = partition(S, self.world)
+        lo, hi = parts[self.rank]
+        ex = self.executor(agg, device)
+        W, hpr = self.world, 16 // self.world
+        if mode == "heads":
+            _, ws_g, xb = ex.heads_workspaces(hi - lo, P, W)
+            for _ in range(layers):
+                works = []
+                for g in xb["groups"]:
+                    sl = [slice(r * hpr + g["h0"], r * hpr + g["h0"] + g["gs"]) for r in range(W)]
+                    works += [self._all_to_all_chunks(list(g["q"].unbind(0)), [ws_g.q[s] for s in sl], async_op=True),
+                              self._all_to_all_chunks(list(g["k"].unbind(0)), [ws_g.k[s] for s in sl], async_op=True),
+                              self._all_to_all_chunks(list(g["vt"].unbind(0)), [ws_g.vt[s] for s in sl], async_op=True)]
+                for g in xb["groups"]:
+                    back = [xb["o_back"][r * hpr + g["h0"]: r * hpr + g["h0"] + g["gs"]] for r in range(W)]
+                    works.append(self._all_to_all_chunks(back, list(g["o"].unbind(0)), async_op=True))
+                for w in works:
+                    w.wait()
+        else:
+            _, ws_g = ex.workspaces(hi - lo, max(h - l for l, h in parts), P)
+            kg, vg = ex.gather_buffers(ws_g, W)
+            for _ in range(layers):
+                wk = self._all_gather(kg.flatten(0, 1), ws_g.k, async_op=True)
+                wv = self._all_gather(vg.flatten(0, 1), ws_g.vt, async_op=True)
+                wk.wait()
+                wv.wait()
+        return mode
 
     def gather_views(self, local, parts):
         """all-gather a (1, n_local, ...) tensor along the view axis (uneven shards padded)."""
@@ -302,5 +431,9 @@ class ViewSharding:
         pad = torch.zeros((1, max_local) + tuple(local.shape[2:]), device=local.device, dtype=local.dtype)
         pad[:, : local.shape[1]] = local
         full = torch.empty((self.world,) + tuple(pad.shape), device=local.device, dtype=local.dtype)
-        self._all_gather(full.flatten(0, 1), pad)
+        skip, self.skip_comm = self.skip_comm, False
+        try:
+            self._all_gather(full.flatten(0, 1), pad)
+        finally:
+            self.skip_comm = skip
         return torch.cat([full[r][:, : h - l] for r, (l, h) in enumerate(parts)], dim=1)

@@ -69,50 +69,57 @@ def attn(args):
 
 
 def gemm(args):
+    """Interleaved A/B of the GEMM workgroup tiles (ovg_linear_params.tile) on the block's four shapes at the bench's M,
+    plus square STORE problems (4096^3 / 8192^3, the guide's reference shapes) that isolate the main loop from the fused
+    epilogues. Every tile's output is compared with tile 1 (128 x 128, itself verified against torch in gpu_selftest.py)."""
     dt = torch.bfloat16
     g = torch.Generator().manual_seed(1)
     out = {}
+    shapes = []
     for S in args.views:
         M = S * 1374
-        for nm, N, K, epi in (("qkv", 3072, 1024, "qkv"), ("proj", 1024, 1024, L.EPI_RES), ("fc1", 4096, 1024, L.EPI_GELU), ("fc2", 1024, 4096, L.EPI_RES)):
-            x = torch.randn(M, K, generator=g).to(dt).to(DEV)
-            w = (torch.randn(N, K, generator=g) * 0.03).to(dt).to(DEV)
-            b = torch.randn(N, generator=g).to(DEV)
-            if epi == "qkv":
-                q, k, vt = ops.alloc_qkv(16, M, M, dt, DEV)
-                qn = [torch.ones(64, device=DEV), torch.zeros(64, device=DEV), torch.ones(64, device=DEV), torch.zeros(64, device=DEV)]
-                from omnivggt_official_amd.aggregator import make_rope_tables
-                rope = make_rope_tables(38, DEV)
-                fn = lambda: ops.qkv(x, w, b, M, dt, q, k, vt, qk_norm=qn, rope=rope)
-            elif epi == L.EPI_RES:
-                res = torch.randn(M, N, generator=g).to(DEV)
-                gam = torch.ones(N, device=DEV)
-                y = torch.empty(M, N, device=DEV)
-                fn = lambda: ops.linear(x, w, b, dt, epilogue=L.EPI_RES, out=y, res=res, gamma=gam)
-            else:
-                y = torch.empty(M, N, device=DEV, dtype=dt)
-                fn = lambda: ops.linear(x, w, b, dt, epilogue=epi, out=y)
-            fn()
-            combos = [(gm, ml) for gm in args.tile_groups for ml in args.mainloops]
-            if args.ablate:
-                # 2/3 = 128^2 LDS-DMA loop without loads / without MFMAs; 5/6 = the same for the 256^2 ping-pong loop (RES epilogue only)
-                combos = [(8, 7), (8, 1), (8, 2), (8, 3), (4, 4), (4, 5), (4, 6)]
-            ts = {c: [] for c in combos}
-            for _ in range(args.rounds):
-                for gm, ml in combos:                  # interleaved A/B of the tuning knobs
-                    L.load().ovg_debug_set(0, gm)
-                    L.load().ovg_debug_set(2, gm if ml >= 4 else 4)     # 256^2 kernels: their own group size
-                    L.load().ovg_debug_set(1, ml)
-                    ts[(gm, ml)].append(timed(fn, 20))
-            L.load().ovg_debug_set(0, 8)
-            L.load().ovg_debug_set(1, 0)
-            L.load().ovg_debug_set(2, 4)
-            for gm, ml in combos:
-                ms = statistics.median(ts[(gm, ml)])
-                tf = 2.0 * M * N * K / ms / 1e9
-                print("gemm %-5s S=%d M=%d N=%d K=%d group=%d mainloop=%d: median %.3f ms  %.1f TFLOP/s (%.1f%% of 2.5PF)"
-                      % (nm, S, M, N, K, gm, ml, ms, tf, tf / 25.0), flush=True)
-                out["gemm_%s_S%d_g%d_ml%d" % (nm, S, gm, ml)] = {"ms": ms, "tflops": tf}
+        shapes += [("qkv", M, 3072, 1024, "qkv"), ("proj", M, 1024, 1024, L.EPI_RES), ("fc1", M, 4096, 1024, L.EPI_GELU), ("fc2", M, 1024, 4096, L.EPI_RES)]
+    for n in args.square:
+        shapes.append(("sq%d" % n, n, n, n, L.EPI_STORE))
+    for nm, M, N, K, epi in shapes:
+        x = torch.randn(M, K, generator=g).to(dt).to(DEV)
+        w = (torch.randn(N, K, generator=g) * 0.03).to(dt).to(DEV)
+        b = torch.randn(N, generator=g).to(DEV)
+        if epi == "qkv":
+            q, k, vt = ops.alloc_qkv(16, M, M, dt, DEV)
+            qn = [torch.ones(64, device=DEV), torch.zeros(64, device=DEV), torch.ones(64, device=DEV), torch.zeros(64, device=DEV)]
+            from omnivggt_official_amd.aggregator import make_rope_tables
+            rope = make_rope_tables(38, DEV)
+            fn = lambda t: ops.qkv(x, w, b, M, dt, q, k, vt, qk_norm=qn, rope=rope, tile=t)
+            result = lambda: torch.cat([q.flatten(), k.flatten(), vt.flatten()]).float()
+        elif epi == L.EPI_RES:
+            res = torch.randn(M, N, generator=g).to(DEV)
+            gam = torch.ones(N, device=DEV)
+            y = torch.empty(M, N, device=DEV)
+            fn = lambda t: ops.linear(x, w, b, dt, epilogue=L.EPI_RES, out=y, res=res, gamma=gam, tile=t)
+            result = lambda: y.float().clone()
+        else:
+            y = torch.empty(M, N, device=DEV, dtype=dt)
+            fn = lambda t: ops.linear(x, w, b, dt, epilogue=epi, out=y, tile=t)
+            result = lambda: y.float().clone()
+        fn(1)
+        ref = result()
+        errs = {}
+        for t in args.tiles:
+            fn(t)
+            errs[t] = float((result() - ref).abs().max() / ref.abs().max())
+        ts = {t: [] for t in args.tiles}
+        flop = 2.0 * M * N * K
+        iters = max(3, int(args.target_ms / max(1e-3, flop / 800e12 * 1e3)))
+        for _ in range(args.rounds):
+            for t in args.tiles:                       # interleaved A/B
+                ts[t].append(timed(lambda: fn(t), iters))
+        for t in args.tiles:
+            ms = statistics.median(ts[t])
+            tf = flop / ms / 1e9
+            print("gemm %-7s M=%-6d N=%-5d K=%-5d tile=%d: median %.4f ms (min %.4f)  %.1f TFLOP/s (%.1f%% of 2.5PF)  err_vs_tile1=%.2e"
+                  % (nm, M, N, K, t, ms, min(ts[t]), tf, tf / 25.0, errs[t]), flush=True)
+            out["gemm_%s_M%d_tile%d" % (nm, M, t)] = {"ms": ms, "tflops": tf, "err": errs[t]}
     return out
 
 
@@ -123,9 +130,8 @@ def main():
     ap.add_argument("--variants", type=int, nargs="+", default=[1, 6, 8, 21, 25], help="see dispatch16 in ovg_attn.hip")
     ap.add_argument("--modes", nargs="+", default=["global", "frame"])
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--tile-groups", type=int, nargs="+", default=[8])
-    ap.add_argument("--mainloops", type=int, nargs="+", default=[0], help="0 = automatic, 7 = 128^2 register-staged, 1 = 128^2 LDS-DMA, 4 = 256^2 ping-pong")
-    ap.add_argument("--ablate", action="store_true", help="GEMM: also time the LDS-DMA loop without loads / without MFMAs")
+    ap.add_argument("--tiles", type=int, nargs="+", default=[1, 2], help="GEMM: ovg_linear_params.tile values to compare (1 = 128^2, 2 = 256^2 ping-pong, ...)")
+    ap.add_argument("--square", type=int, nargs="*", default=[], help="GEMM: also time n^3 STORE problems (e.g. 4096 8192)")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--target-ms", type=float, default=20.0)
     ap.add_argument("--out", default="")

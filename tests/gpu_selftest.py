@@ -453,6 +453,206 @@ def test_block(quick):
             report("block_%s_%s" % (name, mode), buf[:, 1024:], ref, tol)
 
 
+# ---------------------------------------------------------------------------
+# The kernels the 64-view bench actually runs (VERDICT r1 "close the parity hole under the headline number"):
+# the 256 x 256 ping-pong GEMMs forced through `tile`, every epilogue, ragged M, and global attention at the
+# real key counts.
+# ---------------------------------------------------------------------------
+def test_gemm256(quick):
+    """linear256_kernel<STORE|GELU|RES(+inject)|PATCH> and qkv256_kernel (all three `part`s), forced with
+    tile = OVG_TILE_256, against the same CPU f32 references as the 128 x 128 path; M % 256 != 0 everywhere."""
+    g = torch.Generator().manual_seed(13)
+    T256 = L.TILE_256
+    for name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        tol = TOL[name]
+        shapes = [(777, 1024, 1024), (33000, 4096, 1024), (33000, 1024, 4096)]
+        if not quick and name == "bf16":
+            shapes.append((64 * 1374, 4096, 1024))        # the bench's own M: 344 x 16 = 5504 workgroups, XCD remap at full size
+        for (M, N, K) in shapes:
+            x = rnd(M, K, g=g).to(dt)
+            w = (rnd(N, K, g=g) * (0.05 if K == 1024 else 0.025)).to(dt)
+            bias = rnd(N, g=g)
+            base = x.float() @ w.float().t() + bias
+            xd, wd, bd = x.to(DEV), w.to(DEV), bias.to(DEV)
+            tag = "%s_%dx%dx%d" % (name, M, N, K)
+            if M <= 33000:
+                y = ops.linear(xd, wd, bd, dt, tile=T256)
+                report("gemm256_store_" + tag, y, base, tol)
+                y = ops.linear(xd, wd, bd, dt, out_f32=True, tile=T256)
+                report("gemm256_store_f32out_" + tag, y, base, 2e-5)
+            y = ops.linear(xd, wd, bd, dt, epilogue=L.EPI_GELU, tile=T256)
+            report("gemm256_gelu_" + tag, y, F.gelu(base), tol)
+            if N == 1024:
+                res = rnd(M, 2 * N, g=g)
+                gamma = rnd(N, g=g)
+                per = 1374
+                inj = rnd((M + per - 1) // per, N, g=g)
+                ref = res[:, N:] + gamma * base
+                resd = res.to(DEV)
+                out = torch.zeros(M, 2 * N, device=DEV)
+                ops.linear(xd, wd, bd, dt, epilogue=L.EPI_RES, out=out[:, :N], res=resd[:, N:], gamma=gamma.to(DEV), tile=T256)
+                report("gemm256_res_" + tag, out[:, :N], ref, 2e-5)
+                ref2 = ref.clone()
+                ref2[::per] += inj[: ref2[::per].shape[0]]
+                ops.linear(xd, wd, bd, dt, epilogue=L.EPI_RES, out=out[:, :N], res=resd[:, N:], gamma=gamma.to(DEV), inject=inj.to(DEV),
+                           inj_period=per, tile=T256)
+                report("gemm256_res_inject_" + tag, out[:, :N], ref2, 2e-5)
+                # in place on the residual stream (x_out aliases res), as ovg_block_forward's fc2 runs it
+                buf = resd[:, N:].clone()
+                ops.linear(xd, wd, bd, dt, epilogue=L.EPI_RES, out=buf, res=buf, gamma=gamma.to(DEV), tile=T256)
+                report("gemm256_res_inplace_" + tag, buf, ref, 2e-5)
+        # automatic choice == forced choice where the heuristic picks 256 (M >= 32768, light epilogue): bit-identical
+        x = rnd(33000, 1024, g=g).to(dt).to(DEV)
+        w = (rnd(4096, 1024, g=g) * 0.05).to(dt).to(DEV)
+        b = rnd(4096, g=g).to(DEV)
+        ya, yf, y1 = ops.linear(x, w, b, dt), ops.linear(x, w, b, dt, tile=T256), ops.linear(x, w, b, dt, tile=L.TILE_128)
+        report("gemm256_auto_is_256_%s" % name, ya, yf.float(), 0.0)
+        report("gemm256_vs_128_%s" % name, yf, y1.float(), tol)
+        # PATCH epilogue (DINO patch embed: K = 640, rows remapped past the 5 special tokens)
+        p0, p1 = 1369, 1374
+        M, N, K = 3 * p0, 1024, 640
+        x = rnd(M, K, g=g).to(dt)
+        w = (rnd(N, K, g=g) * 0.05).to(dt)
+        bias = rnd(N, g=g)
+        table = rnd(p0 + 1, N, g=g)
+        base = x.float() @ w.float().t() + bias
+        ref = torch.zeros(3 * p1, N)
+        for v in range(3):
+            ref[v * p1 + 5: v * p1 + 5 + p0] = base[v * p0:(v + 1) * p0] + table[1:]
+        out = torch.zeros(3 * p1, N, device=DEV)
+        ops.linear(x.to(DEV), w.to(DEV), bias.to(DEV), dt, epilogue=L.EPI_PATCH, out=out, table=table.to(DEV), p0=p0, p1=p1, row_off=5, tile=T256)
+        report("gemm256_patch_%s" % name, out, ref, 2e-5)
+        # an illegal forced tile is refused, not silently replaced
+        try:
+            ops.linear(x.to(DEV)[:, :640], w.to(DEV)[:128], None, dt, tile=T256)
+            results.append({"name": "gemm256_illegal_n_refused_" + name, "ok": False, "rel": float("nan")})
+            print("[FAIL] tile=256 with N=128 was accepted")
+        except L.OvgError:
+            results.append({"name": "gemm256_illegal_n_refused_" + name, "ok": True, "rel": 0.0})
+
+    # fused QKV: 24 views (M = 32 976 = 128 x 256 + 208), global and frame sequences, part 0 / 1 + 2
+    tpv, gw = 1374, 37
+    cos, sin = orc.rope_tables(38)
+    cos16, sin16 = cos[:, :16].contiguous().to(DEV), sin[:, :16].contiguous().to(DEV)
+    for name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        nviews = 24
+        M = nviews * tpv
+        x = rnd(M, 1024, g=g).to(dt)
+        w = (rnd(3072, 1024, g=g) * 0.03).to(dt)
+        bias = rnd(3072, g=g) * 0.1
+        qn = [rnd(64, g=g) * 0.1 + 1.5, rnd(64, g=g) * 0.1, rnd(64, g=g) * 0.1 + 1.5, rnd(64, g=g) * 0.1]
+        qnd = [t.to(DEV) for t in qn]
+        xd, wd, bd = x.to(DEV), w.to(DEV), bias.to(DEV)
+        for mode in ("global", "frame"):
+            seq = tpv if mode == "frame" else M
+            qr, kr, vr = qkv_reference(x.float(), w.float(), bias, seq, qn, (cos, sin), tpv, gw)
+            BH = (M // seq) * 16
+            tol = TOL[name] * 2
+            q, k, vt = ops.alloc_qkv(BH, seq, seq, dt, DEV)
+            ops.qkv(xd, wd, bd, seq, dt, q, k, vt, qk_norm=qnd, rope=(cos16, sin16), tile=T256)
+            report("qkv256_%s_%s.q" % (name, mode), q[:, :seq], qr.reshape(BH, seq, 64), tol)
+            report("qkv256_%s_%s.k" % (name, mode), k[:, :seq], kr.reshape(BH, seq, 64), tol)
+            report("qkv256_%s_%s.vt" % (name, mode), vt[:, :, :seq], vr.reshape(BH, seq, 64).transpose(1, 2), tol)
+            ok_pad = float(q[:, seq:].abs().max()) == 0.0 and float(k[:, seq:].abs().max()) == 0.0 and float(vt[:, :, seq:].abs().max()) == 0.0
+            results.append({"name": "qkv256_%s_%s.padding_untouched" % (name, mode), "ok": ok_pad, "rel": 0.0})
+            if not ok_pad:
+                print("[FAIL] qkv256 wrote padding rows")
+            q2, k2, vt2 = ops.alloc_qkv(BH, seq, seq, dt, DEV)
+            ops.qkv(xd, wd, bd, seq, dt, q2, k2, vt2, qk_norm=qnd, rope=(cos16, sin16), part=1, tile=T256)
+            kv_only = float(q2.abs().max()) == 0.0
+            ops.qkv(xd, wd, bd, seq, dt, q2, k2, vt2, qk_norm=qnd, rope=(cos16, sin16), part=2, tile=T256)
+            same = kv_only and torch.equal(q2, q) and torch.equal(k2, k) and torch.equal(vt2, vt)
+            results.append({"name": "qkv256_%s_%s.part1+part2==part0" % (name, mode), "ok": bool(same), "rel": 0.0})
+            print("[%s] qkv256_%s_%s part 1 + part 2 == part 0 (bitwise), part 1 leaves q alone" % ("PASS" if same else "FAIL", name, mode), flush=True)
+            if mode == "global":       # the automatic choice at this M is the 256 kernel as well
+                q3, k3, vt3 = ops.alloc_qkv(BH, seq, seq, dt, DEV)
+                ops.qkv(xd, wd, bd, seq, dt, q3, k3, vt3, qk_norm=qnd, rope=(cos16, sin16))
+                results.append({"name": "qkv256_%s_auto_is_256" % name, "ok": bool(torch.equal(q3, q) and torch.equal(k3, k) and torch.equal(vt3, vt)), "rel": 0.0})
+
+
+def _attn_ref_rows_gpu(q, k, v, rows):
+    """f32 softmax(q k^T) v on the DEVICE with plain torch ops for the selected query rows of every head (base-2 logits)."""
+    qs = q[:, rows].float()
+    s = torch.matmul(qs, k.float().transpose(1, 2)) * math.log(2.0)
+    return torch.matmul(torch.softmax(s, dim=-1), v.float())
+
+
+def test_attn_big(quick):
+    """Global attention at the bench's key counts: N = 10 992 (8 views) and 21 984 (16 views) in FULL against a plain
+    torch f32 evaluation (device, head by head), N = 87 936 (64 views) on sampled query rows -- first / last workgroup,
+    a 256-row tile boundary, rows spread over every XCD's share of the grid -- plus a float64 CPU evaluation of a few
+    rows for independence from the device BLAS. Variants: default (speculative), lazy-rescale, forced fallback."""
+    g = torch.Generator().manual_seed(17)
+    cases = [("bf16", torch.bfloat16, 8, (0, 6, 18)), ("f16", torch.float16, 8, (0, 21)), ("bf16", torch.bfloat16, 16, (0,))]
+    if not quick:
+        cases.append(("bf16", torch.bfloat16, 64, (0, 6, 18)))
+        cases.append(("f16", torch.float16, 64, (0,)))
+    for name, dt, S, variants in cases:
+        n = S * 1374
+        BH = 16
+        q, k, vt = ops.alloc_qkv(BH, n, n, dt, DEV)
+        q[:, :n] = (torch.randn(BH, n, 64, generator=g) * 1.2).to(dt).to(DEV)
+        k[:, :n] = torch.randn(BH, n, 64, generator=g).to(dt).to(DEV)
+        v = torch.randn(BH, n, 64, generator=g).to(dt).to(DEV)
+        vt[:, :, :n] = v.transpose(1, 2)
+        if S <= 16:
+            rows = torch.arange(n, device=DEV)
+        else:
+            pick = set(range(0, 260)) | set(range(n - 300, n))
+            for t in range(1, 8):
+                base = (n * t // 8) // 256 * 256
+                pick |= set(range(base - 3, base + 4))
+            pick |= set(range(17, n, 1009))
+            rows = torch.tensor(sorted(pick), device=DEV)
+        ref = torch.cat([_attn_ref_rows_gpu(q[h:h + 1, :n], k[h:h + 1, :n], v[h:h + 1], rows) for h in range(BH)])   # [16, R, 64]
+        ref_tok = ref.permute(1, 0, 2).reshape(rows.numel(), 1024)
+        # independent float64 check of the reference itself on a few rows (CPU)
+        r64 = rows[:: max(1, rows.numel() // 24)][:24].cpu()
+        s64 = (q[:, r64].double().cpu() @ k[:, :n].double().cpu().transpose(1, 2)) * math.log(2.0)
+        o64 = (torch.softmax(s64, -1) @ v.double().cpu()).permute(1, 0, 2).reshape(r64.numel(), 1024)
+        sel = torch.searchsorted(rows.cpu(), r64)
+        report("attn_big_%s_S%d_device_ref_vs_f64" % (name, S), ref_tok[sel.to(DEV)], o64.float(), 2e-5)
+        for variant in variants:
+            out = ops.flash_attn(q, [(k, vt, n)], n, dt, variant=variant)
+            report("attn_big_%s_S%d_N%d_v%d_%s" % (name, S, n, variant, "full" if S <= 16 else "%drows" % rows.numel()), out[rows], ref_tok, TOL[name])
+        del q, k, vt, v, ref, ref_tok
+        torch.cuda.empty_cache()
+
+
+def test_attn_lse_merge():
+    """Two launches over disjoint key sets + ovg_attn_merge == one launch over all keys (the local-first all-gather
+    path of sharding.py); the per-row log-sum-exp itself against torch.logsumexp; every kernel family."""
+    g = torch.Generator().manual_seed(19)
+    for name, dt in DT.items():
+        BH, nq, nka, nkb = 16, 1374, 1374, 2 * 1374 - 77
+        q = (rnd(BH, nq, 64, g=g) * 1.2).to(dt)
+        ka, kb = rnd(BH, nka, 64, g=g).to(dt), rnd(BH, nkb, 64, g=g).to(dt)
+        va, vb = rnd(BH, nka, 64, g=g).to(dt), rnd(BH, nkb, 64, g=g).to(dt)
+        kall, vall = torch.cat([ka, kb], 1).float(), torch.cat([va, vb], 1).float()
+        ref = attn_reference(q.float(), kall, vall).permute(1, 0, 2).reshape(nq, 1024)
+        lse_ref_a = torch.logsumexp((q.float() @ ka.float().transpose(1, 2)) * math.log(2.0), -1) / math.log(2.0)
+        qd, kad, vtad = ops.alloc_qkv(BH, nq, nka, dt, DEV)
+        _, kbd, vtbd = ops.alloc_qkv(BH, 64, nkb, dt, DEV)
+        qd[:, :nq] = q.to(DEV)
+        kad[:, :nka] = ka.to(DEV); vtad[:, :, :nka] = va.transpose(1, 2).to(DEV)
+        kbd[:, :nkb] = kb.to(DEV); vtbd[:, :, :nkb] = vb.transpose(1, 2).to(DEV)
+        for variant in ((1,) if name == "f32" else (0, 1, 6, 21, 18)):
+            la = torch.full((BH, qd.shape[1]), float("nan"), device=DEV)
+            lb = torch.full((BH, qd.shape[1]), float("nan"), device=DEV)
+            oa = ops.flash_attn(qd, [(kad, vtad, nka)], nq, dt, variant=variant, lse=la)
+            ob = ops.flash_attn(qd, [(kbd, vtbd, nkb)], nq, dt, variant=variant, lse=lb)
+            report("attn_lse_%s_v%d" % (name, variant), la[:, :nq], lse_ref_a, 2e-5 if name == "f32" else 2e-3)
+            merged = ops.attn_merge(oa, la, ob, lb, dt, out=oa)          # in place on launch A's output, like sharding.py
+            report("attn_merge_%s_v%d" % (name, variant), merged, ref, TOL[name] * (1.5 if name != "f32" else 1))
+    # weight pre-pack == torch's own rounding, zero padding
+    w = rnd(1024, 3, 14, 14, g=g)
+    for name, dt in DT.items():
+        got = ops.pack_weights(w.to(DEV), dt, k_pad=640)
+        exp = torch.zeros(1024, 640)
+        exp[:, :588] = w.reshape(1024, -1).to(dt).float()
+        report("pack_weights_%s" % name, got, exp, 0.0)
+
+
 def bench(fn, iters=10, warm=3):
     for _ in range(warm):
         fn()
@@ -526,7 +726,8 @@ def main():
     print(L.load().ovg_build_info().decode(), torch.cuda.get_device_name(0), flush=True)
     tests = {"probe": test_probe, "layernorm": test_layernorm, "linear": lambda: test_linear(args.quick), "qkv": lambda: test_qkv(args.quick),
              "attn": lambda: test_attn(args.quick), "embed": test_embed, "block": lambda: test_block(args.quick),
-             "heads": lambda: test_heads(args.quick)}
+             "heads": lambda: test_heads(args.quick), "gemm256": lambda: test_gemm256(args.quick), "attn_big": lambda: test_attn_big(args.quick),
+             "lse_merge": test_attn_lse_merge}
     for name, fn in tests.items():
         if args.only and name not in args.only.split(","):
             continue

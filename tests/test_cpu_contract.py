@@ -57,7 +57,9 @@ def test_ctypes_struct_layout_matches_c():
              "ovg_dino_specials_params": L.DinoSpecialsParams, "ovg_assemble_params": L.AssembleParams,
              "ovg_copy_rows_params": L.CopyRowsParams, "ovg_head_layernorm_params": L.HeadLayerNormParams,
              "ovg_conv_params": L.ConvParams, "ovg_upsample_params": L.UpsampleParams, "ovg_dpt_out_params": L.DptOutParams,
-             "ovg_unproject_params": L.UnprojectParams, "ovg_heads_to_tokens_params": L.HeadsToTokensParams}
+             "ovg_unproject_params": L.UnprojectParams, "ovg_heads_to_tokens_params": L.HeadsToTokensParams,
+             "ovg_attn_merge_params": L.AttnMergeParams, "ovg_block_workspace": L.BlockWorkspace,
+             "ovg_pack_weights_params": L.PackWeightsParams}
     src = '#include <stdio.h>\n#include "%s"\nint main(){\n' % HEADER
     for name in pairs:
         src += 'printf("%s %%zu\\n", sizeof(%s));\n' % (name, name)
@@ -81,6 +83,47 @@ def test_argument_validation_without_gpu():
     a = L.AttnParams()
     assert lib.ovg_flash_attn(ctypes.byref(a), None) == -1
     assert lib.ovg_qkv(None, None) == -1
+    assert lib.ovg_attn_merge(ctypes.byref(L.AttnMergeParams()), None) == -1
+    assert lib.ovg_pack_weights(ctypes.byref(L.PackWeightsParams()), None) == -1
+    assert not hasattr(lib, "ovg_debug_set")          # ABI 4: no process-global knobs left in the library
+
+
+def test_block_workspace_query_matches_the_python_allocation():
+    """ovg_block_workspace_bytes (caller-provided workspace with a size query) vs what Workspace allocates."""
+    from omnivggt_official_amd import ops
+    for M, seq, dt, e in ((8 * 1374, 1374, torch.bfloat16, 2), (8 * 1374, 8 * 1374, torch.float16, 2), (2 * 1374, 1374, torch.float32, 4)):
+        ws = ops.block_workspace_bytes(M, seq, dt)
+        pad = (seq + 63) // 64 * 64
+        BH = (M // seq) * 16
+        assert ws["xn"] == ws["attn"] == M * 1024 * e and ws["hid"] == M * 4096 * e
+        assert ws["q"] == ws["k"] == ws["vt"] == BH * pad * 64 * e
+        assert ws["total"] == sum(ws[k] for k in ("xn", "attn", "hid", "q", "k", "vt"))
+    p = L.BlockParams()
+    assert L.load().ovg_block_workspace_bytes(ctypes.byref(p), ctypes.byref(L.BlockWorkspace())) == -1
+
+
+def test_stale_library_is_detected(tmp_path, monkeypatch):
+    """lib.load() compares the build stamp with the digest of csrc/ + header + flags: a library built from
+    other sources is rebuilt when hipcc is there and refused otherwise -- never loaded silently."""
+    from omnivggt_official_amd import build as B
+    assert B.is_current()
+    monkeypatch.setattr(B, "_digest", lambda: "0" * 64)
+    assert not B.is_current()
+    monkeypatch.setattr(B, "have_hipcc", lambda: False)
+    monkeypatch.setattr(L, "_lib", None)
+    with pytest.raises(L.OvgError, match="stale"):
+        L.load()
+
+
+def test_shard_mode_is_decided_without_communication():
+    from omnivggt_official_amd.sharding import head_groups, resolve_mode
+    assert resolve_mode("auto", 64, 8, False) == "heads" and resolve_mode("auto", 64, 1, False) == "allgather"
+    assert resolve_mode("auto", 63, 8, False) == "allgather" and resolve_mode("auto", 64, 8, True) == "allgather"
+    assert resolve_mode("allgather", 64, 8, False) == "allgather" and resolve_mode("heads", 128, 4, False) == "heads"
+    for bad in ((63, 8, False), (64, 8, True), (6, 3, False)):
+        with pytest.raises(ValueError):
+            resolve_mode("heads", *bad)
+    assert head_groups(2) == [(0, 1), (1, 1)] and head_groups(1) == [(0, 1)] and head_groups(8) == [(0, 4), (4, 4)]
 
 
 def test_hot_path_fails_loudly_on_cpu():

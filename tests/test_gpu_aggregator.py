@@ -3,9 +3,9 @@ golden vectors of the real reference.
 
 Tolerances (max|a-b| / max|b| per tensor):
   f32 parity mode : <= 1e-4 on every aggregator layer and on pose_enc / depth / points
-  bf16 / f16 modes: reported next to the f32 reference; gated loosely (tokens <= 0.2 / 0.05) because
-                    with the sensitised weights the reference itself moves 7e-2..1e-1 under
-                    torch.autocast(bf16) -- the 1e-4 target is an fp32 statement.
+  bf16 / f16 modes: at full depth, against the f32 reference golden AND the reference's own bf16-autocast twin
+                    (tests/golden/*_bf16twin.npz): gated at <= 2x the twin's error per tensor (SURVEY 8c Gate 2) --
+                    the 1e-4 target is an fp32 statement, the twin itself moves 7e-3..1e-2.
 Heads are stock PyTorch (out of kernel scope) and are exercised in two tests only.
 """
 import os
@@ -159,16 +159,57 @@ def test_f32_full_depth_predictions_vs_reference_golden(full_model, name):
     assert common.max_rel(out["world_points"][0, :, ::37, ::37].cpu(), gold["world_points"]) <= F32_TOL
 
 
-@pytest.mark.parametrize("dtype,tok_tol", [(torch.bfloat16, 0.2), (torch.float16, 0.05)])
-def test_low_precision_modes_vs_golden(full_model, dtype, tok_tol):
-    full_model.set_compute_dtype(dtype)
-    S, dgi, cgi, _ = common.case("s3_partial_aux")
-    toks, start = run_agg(full_model, S, dgi, cgi)
-    gold = common.load_golden("s3_partial_aux")
-    errs = {l: common.max_rel(common.sample_tokens([t.cpu() for t in toks], l), gold["tok_L%d" % l]) for l in common.TOK_LAYERS}
-    print("%s vs f32 reference tokens (max-rel): %s" % (dtype, {k: "%.2e" % v for k, v in errs.items()}))
-    assert all(torch.isfinite(t).all() for t in toks)
-    assert max(errs.values()) <= tok_tol
+TWIN_CASES = ("s2_images_only", "s3_partial_aux", "s2_392x518_aux")
+
+
+def _rms_rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp(min=1e-30))
+
+
+@pytest.mark.parametrize("name", TWIN_CASES)
+def test_low_precision_modes_vs_twin(full_model, name):
+    """SURVEY 8c Gate 2: the 16-bit throughput modes at FULL depth (24 + 24 + 24 blocks, HIP DPT heads) against the f32
+    reference golden AND against the same-precision twin -- the reference itself under torch.autocast('cpu', bfloat16)
+    on the same weights / inputs (oracle/gen_golden_bf16twin.py). Gate: on every aggregator layer and on pose_enc the
+    HIP error vs the f32 reference is <= 2x the twin's own error (max-rel AND rms-rel); the dense predictions, which pass
+    through the 16-bit DPT heads (a "next" row), <= 3x. The measured table is appended to gpurun_out/r02_lowprec_parity.txt."""
+    S, dgi, cgi, hw = common.case(name)
+    gold, twin = common.load_golden(name), common.load_golden(name + "_bf16twin")
+    keys = ["tok_L%d" % l for l in common.TOK_LAYERS] + ["pose_enc", "depth", "depth_conf", "world_points", "world_points_conf"]
+    rows = {k: {"twin": (common.max_rel(twin[k], gold[k]), _rms_rel(twin[k], gold[k]))} for k in keys}
+    for dtype, tag in ((torch.bfloat16, "bf16"), (torch.float16, "f16")):
+        full_model.set_compute_dtype(dtype)
+        full_model.hip_heads = True
+        out = run_full(full_model, S, dgi, cgi, hw=hw)
+        toks, _ = run_agg(full_model, S, dgi, cgi, hw=hw)
+        assert all(torch.isfinite(t).all() for t in toks)
+        got = {"tok_L%d" % l: common.sample_tokens([t.cpu() for t in toks], l) for l in common.TOK_LAYERS}
+        got["pose_enc"] = out["pose_enc"].cpu()
+        got["depth"] = out["depth"][0, :, ::37, ::37, 0].cpu()
+        got["depth_conf"] = out["depth_conf"][0, :, ::37, ::37].cpu()
+        got["world_points"] = out["world_points"][0, :, ::37, ::37].cpu()
+        got["world_points_conf"] = out["world_points_conf"][0, :, ::37, ::37].cpu()
+        for k in keys:
+            rows[k][tag] = (common.max_rel(got[k], gold[k]), _rms_rel(got[k], gold[k]))
+            rows[k][tag + "_vs_twin"] = common.max_rel(got[k], twin[k])
+    full_model.set_compute_dtype(torch.float32)
+    lines = ["case %s (S=%d, %s): error vs the f32 REFERENCE golden as max-rel / rms-rel; last columns: HIP vs the twin itself" % (name, S, hw),
+             "%-18s %-21s %-21s %-21s %-10s %-10s" % ("tensor", "reference@bf16-autocast", "HIP bf16", "HIP f16", "bf16~twin", "f16~twin")]
+    for k in keys:
+        r = rows[k]
+        lines.append("%-18s %.2e / %.2e   %.2e / %.2e   %.2e / %.2e   %.2e   %.2e"
+                     % (k, r["twin"][0], r["twin"][1], r["bf16"][0], r["bf16"][1], r["f16"][0], r["f16"][1], r["bf16_vs_twin"], r["f16_vs_twin"]))
+    text = "\n".join(lines)
+    print(text)
+    os.makedirs(os.path.join(common.ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(common.ROOT, "gpurun_out", "r02_lowprec_parity.txt"), "a") as fh:
+        fh.write(text + "\n\n")
+    for k in keys:
+        factor = 2.0 if (k.startswith("tok_") or k == "pose_enc") else 3.0
+        for tag in ("bf16", "f16"):
+            assert rows[k][tag][0] <= factor * rows[k]["twin"][0], (k, tag, "max-rel", rows[k])
+            assert rows[k][tag][1] <= factor * rows[k]["twin"][1], (k, tag, "rms-rel", rows[k])
 
 
 def test_view_permutation_equivariance_at_bench_size():

@@ -61,6 +61,23 @@ def test_dpt_head_kernels_and_whole_head():
     _assert_clean()
 
 
+def test_gemm256_kernels_every_epilogue_ragged_m():
+    """The 256 x 256 ping-pong GEMMs the 64-view bench runs (qkv256_kernel, linear256_kernel<GELU|RES|STORE|PATCH>)."""
+    st.test_gemm256(False)
+    _assert_clean()
+
+
+def test_global_attention_at_bench_key_counts():
+    """N = 10 992 / 21 984 in full, N = 87 936 on sampled rows: the launches the bench times."""
+    st.test_attn_big(False)
+    _assert_clean()
+
+
+def test_attention_lse_output_and_merge_and_weight_pack():
+    st.test_attn_lse_merge()
+    _assert_clean()
+
+
 def test_loaded_library_is_the_in_tree_one():
     import os
     assert os.path.samefile(L.LIB_PATH, os.path.join(os.path.dirname(L.__file__), "libomnivggt_hip.so"))

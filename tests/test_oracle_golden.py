@@ -45,3 +45,15 @@ def test_sensitised_weights_make_the_trunk_visible():
     gold = common.load_golden("s2_full_aux")
     am = gold["tok_absmean"]
     assert am[-1] > 1.2 * am[0] or am[-1] < 0.8 * am[0] or abs(am[12] - am[0]) > 0.1 * am[0]
+
+
+def test_bf16_twin_fixtures_are_present_and_sane():
+    """SURVEY 8c Gate 2: the reference under torch.autocast('cpu', bfloat16) (oracle/gen_golden_bf16twin.py) moves the
+    sampled tokens by 5e-3..2e-2 against its own f32 run on these weights -- the yard-stick of the 16-bit GPU gates."""
+    rep = json.load(open(os.path.join(common.GOLD, "bf16twin_report.json")))
+    for name in ("s2_images_only", "s3_partial_aux", "s2_392x518_aux"):
+        twin, gold = common.load_golden(name + "_bf16twin"), common.load_golden(name)
+        for l in common.TOK_LAYERS:
+            e = common.max_rel(twin["tok_L%d" % l], gold["tok_L%d" % l])
+            assert 1e-3 < e < 5e-2, (name, l, e)
+            assert abs(e - rep[name]["twin_vs_f32_reference"]["tok_L%d" % l]["max_rel"]) < 1e-9

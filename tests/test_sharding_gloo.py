@@ -84,15 +84,30 @@ class OracleExecutor:
     def global_q(self, i, ws, x_in, x_out):
         ws.q[:, : self._q.shape[1]] = self._q
 
-    def global_rest(self, i, ws, x_in, x_out, kg, vg, counts, rank):
-        pre = "aggregator.global_blocks.%d" % i
-        n = x_in.shape[0]
-        keys = torch.cat([kg[r][:, :c] for r, c in enumerate(counts)], dim=1)          # rank order
-        vals = torch.cat([vg[r][:, :, :c].transpose(1, 2) for r, c in enumerate(counts)], dim=1)
+    @staticmethod
+    def _attend(q, keys, vals):
+        """softmax attention in base 2 (q pre-scaled by log2 e) + the per-row log2-sum-exp, like the HIP kernel."""
+        s = q @ keys.transpose(1, 2)                                   # [16, n, nk] log2-domain logits
+        lse = torch.logsumexp(s * math.log(2.0), dim=-1) / math.log(2.0)
+        return torch.softmax(s * math.log(2.0), dim=-1) @ vals, lse
+
+    def attend_local(self, i, ws, n, want_lse):
+        o, lse = self._attend(ws.q[:, :n], ws.k[:, :n], ws.vt[:, :, :n].transpose(1, 2))
+        self._oa, self._lse_a = o, lse
+
+    def attend_remote(self, i, ws, kg, vg, counts, rank, n):
         assert torch.equal(kg[rank], ws.k) and torch.equal(vg[rank], ws.vt)
-        s = (ws.q[:, :n] @ keys.transpose(1, 2)) * math.log(2.0)
-        o = (torch.softmax(s, dim=-1) @ vals).permute(1, 0, 2).reshape(n, 1024)
-        self._post(i, x_in, x_out, o)
+        keys = torch.cat([kg[r][:, :c] for r, c in enumerate(counts) if r != rank], dim=1)
+        vals = torch.cat([vg[r][:, :, :c].transpose(1, 2) for r, c in enumerate(counts) if r != rank], dim=1)
+        self._ob, self._lse_b = self._attend(ws.q[:, :n], keys, vals)
+
+    def merge_finish(self, i, ws, x_in, x_out, n, merged):
+        o = self._oa
+        if merged:                                                     # ovg_attn_merge's formula
+            m = torch.maximum(self._lse_a, self._lse_b)
+            wa, wb = torch.exp2(self._lse_a - m).unsqueeze(-1), torch.exp2(self._lse_b - m).unsqueeze(-1)
+            o = (wa * self._oa + wb * self._ob) / (wa + wb)
+        self._post(i, x_in, x_out, o.permute(1, 0, 2).reshape(n, 1024))
 
     def _post(self, i, x_in, x_out, o):
         pre = "aggregator.global_blocks.%d" % i
@@ -101,11 +116,13 @@ class OracleExecutor:
         x_out.copy_(x + m * self.sd[pre + ".ls2.gamma"])
 
     # ---- head-parallel (all-to-all) mode ----
-    def heads_workspaces(self, n_local, P):
+    def heads_workspaces(self, n_local, P, world):
         ws, _ = self.workspaces(n_local, n_local, P)
-        ex = {"q": torch.full_like(ws.q, float("nan")), "k": torch.full_like(ws.k, float("nan")), "vt": torch.full_like(ws.vt, float("nan")),
-              "o": torch.full_like(ws.q, float("nan")), "o_back": torch.full_like(ws.q, float("nan"))}
-        return ws, ws, ex
+        pad = ws.q.shape[1]
+        nan = lambda *s: torch.full(s, float("nan"))
+        groups = [{"h0": h0, "gs": gs, "q": nan(world, gs, pad, 64), "k": nan(world, gs, pad, 64), "vt": nan(world, gs, 64, pad),
+                   "o": nan(world, gs, pad, 64)} for h0, gs in sharding.head_groups(16 // world)]
+        return ws, ws, {"groups": groups, "o_back": nan(16, pad, 64)}
 
     def global_qkv(self, i, ws, x_in, x_out):
         self.global_kv(i, ws, x_in, x_out)
@@ -114,16 +131,18 @@ class OracleExecutor:
         return ws.q, ws.k, ws.vt
 
     def head_attention(self, qr, kr, vr, out, n, world):
-        hpr = qr.shape[0] // world
-        for bh in range(qr.shape[0]):
-            h = bh % hpr
-            keys = torch.cat([kr[r * hpr + h][:n] for r in range(world)], dim=0)
-            vals = torch.cat([vr[r * hpr + h][:, :n].t() for r in range(world)], dim=0)
-            s = (qr[bh][:n] @ keys.t()) * math.log(2.0)
-            out[bh][:n] = torch.softmax(s, dim=-1) @ vals
+        gs = qr.shape[1]
+        for s in range(world):
+            for h in range(gs):
+                keys = torch.cat([kr[r, h][:n] for r in range(world)], dim=0)
+                vals = torch.cat([vr[r, h][:, :n].t() for r in range(world)], dim=0)
+                sc = (qr[s, h][:n] @ keys.t()) * math.log(2.0)
+                out[s, h].zero_()
+                out[s, h][:n] = torch.softmax(sc, dim=-1) @ vals
         return out
 
     def global_finish(self, i, ws, x_in, x_out, o_back, n):
+        assert not torch.isnan(o_back[:, :n]).any()                   # every head of every group came back
         self._post(i, x_in, x_out, o_back[:, :n].permute(1, 0, 2).reshape(n, 1024))
 
 
@@ -145,15 +164,22 @@ def _worker(rank, world, port, S, dgi, cgi, result_dir, hw=518, mode="auto"):
         sd = common.reduced_state_dict(DEPTH, DINO)
         inp = orc.synthetic_inputs(S, hw=hw)
         sh = sharding.ViewSharding(executor_factory=lambda agg, dev: OracleExecutor(sd, DEPTH), gather_output=True,
-                                   mode="auto" if mode == "choose" else mode)
+                                   mode="auto" if mode == "choose" else ("heads" if mode == "heads_bad" else mode))
         fa = FakeAgg()
         fwd = lambda: sh.forward(fa, inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
-        if mode == "choose":                           # bench.py's self-check: both exchange forms, agree, pin the all-to-all
-            rep = sh.choose_mode(lambda: fwd()[0][-1], S)
-            assert rep["exchange"] == "head-parallel all-to-all" and rep["selfcheck_max_rel_vs_allgather"] < 1e-5, rep
-            assert sh.mode == "heads"
+        if mode == "choose":                           # bench.py's diagnostic: both exchange forms on the same input must agree
+            rep = sh.compare_modes(lambda: fwd()[0][-1], S)
+            assert rep["modes"] == ["allgather", "heads"] and rep["max_rel_heads_vs_allgather"] < 1e-5, rep
+            assert sh.mode == "auto"
+        if mode == "heads_bad":                        # impossible request: every rank raises BEFORE any collective
+            with pytest.raises(ValueError):
+                fwd()
+            dist.barrier()                             # ... and the group is still usable afterwards
+            sh.mode = "auto"
         outs, start = fwd()
         assert start == 5 and sh.last_partition == sharding.partition(S, world)
+        expect = {"heads_bad": "allgather", "choose": "heads", "auto": "heads" if S % world == 0 else "allgather"}.get(mode, mode)
+        assert sh.last_mode == expect, (sh.last_mode, expect)
         if rank == 0:
             torch.save([o.clone() for o in outs], os.path.join(result_dir, "sharded.pt"))
     finally:
@@ -167,10 +193,12 @@ def _free_port():
 
 
 @pytest.mark.parametrize("S,dgi,cgi,hw,mode", [(3, [1], [0, 2], 518, "auto"), (3, [0], [1], (266, 350), "allgather"),
-                                                 (2, [1], [0, 1], (266, 350), "choose"), (4, [0, 3], [1, 2], (210, 266), "heads")])
+                                                 (2, [1], [0, 1], (266, 350), "choose"), (4, [0, 3], [1, 2], (210, 266), "heads"),
+                                                 (3, [], [0], (210, 266), "heads_bad")])
 def test_view_sharded_forward_matches_monolithic_oracle(tmp_path, S, dgi, cgi, hw, mode):
-    """2 ranks: uneven splits (3 views -> K/V all-gather path) and even splits (-> head-parallel all-to-all path,
-    8 heads per rank); non-square, non-trained patch grids in all but the first case."""
+    """2 ranks: uneven splits (3 views -> K/V all-gather path: local-first launch, remote launch, log-sum-exp merge)
+    and even splits (-> head-parallel all-to-all path, 8 heads per rank in two pipelined groups of 4); non-square,
+    non-trained patch grids in all but the first case; an impossible explicit mode fails before any collective."""
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), S, dgi, cgi, str(tmp_path), hw, mode), nprocs=world, join=True)
     sharded = torch.load(os.path.join(str(tmp_path), "sharded.pt"))
