@@ -91,7 +91,7 @@ int ovg_layernorm(const ovg_layernorm_params*, void* stream);
  * ------------------------------------------------------------------ */
 enum { OVG_EPI_STORE = 0, OVG_EPI_GELU = 1, OVG_EPI_RES = 2, OVG_EPI_PATCH = 3 };
 /* workgroup tile of the GEMM kernels: 128 x 128 (4 waves, register-staged, 2 workgroups per CU) or 256 x 256
- * (8 waves, LDS-DMA ring, 16-bit dtypes); AUTO picks by shape (ovg_gemm.hip: use_256) */
+ * (8 waves, LDS-DMA ring, 16-bit dtypes); AUTO picks by shape (ovg_gemm.hip: choose_256) */
 enum { OVG_TILE_AUTO = 0, OVG_TILE_128 = 1, OVG_TILE_256 = 2 };
 typedef struct {
   const void* x; int64_t ldx;
@@ -117,7 +117,7 @@ int ovg_linear(const ovg_linear_params*, void* stream);
  * Row m of X is token n = m % seq of batch b = m / seq; RoPE positions are
  * derived from t = m % tokens_per_view: t < 5 -> (0,0) else
  * (1 + (t-5)/grid_w, 1 + (t-5)%grid_w)   (omnivggt_aggregator.py:215-224).
- * rope_cos/rope_sin: f32 [max_pos,16] (rope.py:86-117, 16 unique freqs).
+ * rope_cos/rope_sin: f32 [max_pos,16] (rope.py:86-117, 16 unique freqs), max_pos <= 128 (staged in LDS).
  * Padding rows/cols of q,k,vt are never written (caller zero-fills once).
  * ------------------------------------------------------------------ */
 typedef struct {

@@ -56,7 +56,7 @@ OVG_DEV void tile_coords(int lid, int mtiles, int ntiles_gm, int& tm, int& tn) {
 // ---------------------------------------------------------------------------
 // Main loop: leaves acc[nt][mt] = C[n = n0w + 16nt + 4g + r][m = m0w + 16mt + (lane&15)]
 // ---------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool SWAP = false>   // SWAP: operands trade places, every 16 x 16 block transposed (see ovg_gemm256.h)
 OVG_DEV void gemm_mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict__ W, int64_t ldw,
                            int M, int N, int K, int m0, int n0, unsigned char* lds, f32x4 (&acc)[4][4]) {
   constexpr int BKB = 128;                       // bytes of k per step
@@ -121,7 +121,10 @@ OVG_DEV void gemm_mainloop(const T* __restrict__ X, int64_t ldx, const T* __rest
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) TT<T>::mma(acc[nt][mt], a[nt], b[mt]);
+        for (int mt = 0; mt < 4; ++mt) {
+          if constexpr (SWAP) TT<T>::mma(acc[nt][mt], b[mt], a[nt]);
+          else TT<T>::mma(acc[nt][mt], a[nt], b[mt]);
+        }
     }
     __syncthreads();
     if (more) {
@@ -139,45 +142,104 @@ OVG_DEV void gemm_mainloop(const T* __restrict__ X, int64_t ldx, const T* __rest
 // Linear epilogues (STORE / GELU / RES / PATCH) on a wave's 64(n) x 16*MT(m) accumulator block:
 // acc[nt][mt] = C[n = n_w0 + 16nt + 4g + r][m = m_w0 + 16mt + (lane&15)]
 // ---------------------------------------------------------------------------
-template <typename T, int EPI, bool OUT_F32, int MT>
-OVG_DEV void linear_epilogue(const ovg_linear_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int n_w0) {
+// Written for memory-level parallelism (r02 finding, profiles/r02_gemm_epilogue_mlp.txt): the first version tested
+// `if (p.bias)` / `if (inj)` / `if (m >= M) continue` inside the unrolled tile loops, hipcc turned every (mt, nt) step
+// into load -> s_waitcnt vmcnt(0) -> use, and a 256 x 256 tile spent 10 us (bias), 13 us (GELU) or 36 us (residual)
+// in its epilogue -- one exposed memory round trip per 16 x 16 block -- against 26 us of K = 1024 main loop.
+// Now: the per-column vectors (bias, gamma) are loaded ONCE per wave, the row loop bodies are branch-free (row
+// indices clamped for the loads, only the store is predicated), so the four residual / table loads of a row block
+// -- and, registers permitting, the next row block's -- are in flight together.
+template <typename T, int EPI, bool OUT_F32, int MT, bool INJECT>
+OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int n_w0) {
   const int M = (int)p.M, N = (int)p.N;
   const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
+  const int ncol = n_w0 + 4 * g;                       // this lane's first column of n-block 0; block nt adds 16 nt
+  f32x4 bias[4], gam[4];
+  if (p.bias != nullptr) {                             // wave-uniform, outside every loop
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bias[nt] = *reinterpret_cast<const f32x4*>(p.bias + ncol + nt * 16);
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bias[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if constexpr (EPI == OVG_EPI_RES) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) gam[nt] = *reinterpret_cast<const f32x4*>(p.gamma + ncol + nt * 16);
+  }
+  // row-block operands (residual / position-table rows, injection rows) are fetched ONE ROW BLOCK AHEAD by hand: the
+  // output may alias the residual (fc2 runs in place), so the compiler may not move a later block's loads above an
+  // earlier block's stores on its own; different row blocks never touch the same rows, so doing it by hand is safe.
+  constexpr bool kRowLoads = (EPI == OVG_EPI_RES || EPI == OVG_EPI_PATCH);
+  f32x4 ex_cur[4], ex_nxt[4], inj_cur[4], inj_nxt[4];
+  float on_cur = 0.f, on_nxt = 0.f;
+  int64_t orow_cur = 0, orow_nxt = 0;
+  auto fetch = [&](int mt, f32x4 (&ex)[4], f32x4 (&inj)[4], float& on, int64_t& orow) {
+    const int m = m_w0 + mt * 16 + lr;
+    const int mc = m < M ? m : M - 1;                  // loads of dead rows read a live row instead of branching
+    orow = mc;
+    if constexpr (EPI == OVG_EPI_PATCH) {
+      const int vw = mc / (int)p.p0, t = mc - vw * (int)p.p0;
+      orow = (int64_t)vw * p.p1 + p.row_off + t;
+      const float* trow = p.table + (int64_t)(t + 1) * N + ncol;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) ex[nt] = *reinterpret_cast<const f32x4*>(trow + nt * 16);
+    }
+    if constexpr (EPI == OVG_EPI_RES) {
+      const float* rrow = p.res + (int64_t)mc * p.ldres + ncol;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) ex[nt] = *reinterpret_cast<const f32x4*>(rrow + nt * 16);
+      if constexpr (INJECT) {
+        // camera-token injection (omnivggt_aggregator.py:284-301) on rows m % period == 0: every lane reads ITS view's
+        // row (an L1 / L2 hit: 1 row per 1374) and scales it by 0 or 1 -- no divergent branch in the row loop
+        const int per = (int)p.inj_period, vw = mc / per;
+        on = (mc - vw * per == 0) ? 1.0f : 0.0f;
+        const float* irow = p.inject + (int64_t)vw * N + ncol;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) inj[nt] = *reinterpret_cast<const f32x4*>(irow + nt * 16);
+      }
+    }
+  };
+  fetch(0, ex_cur, inj_cur, on_cur, orow_cur);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int m = m_w0 + mt * 16 + lr;
-    if (m >= M) continue;
-    int64_t orow = m;
-    int trow = 0;
-    bool inj = false;
-    if constexpr (EPI == OVG_EPI_PATCH) {
-      const int v = m / (int)p.p0, t = m % (int)p.p0;
-      orow = (int64_t)v * p.p1 + p.row_off + t;
-      trow = t + 1;
-    }
-    if constexpr (EPI == OVG_EPI_RES) { inj = (p.inject != nullptr) && (m % (int)p.inj_period == 0); }
+    if (kRowLoads && mt + 1 < MT) fetch(mt + 1, ex_nxt, inj_nxt, on_nxt, orow_nxt);
+    const bool ok = (m_w0 + mt * 16 + lr) < M;
+    f32x4 v[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      const int n = n_w0 + nt * 16 + 4 * g;
-      f32x4 v = acc[nt][mt];
-      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      v[nt] = acc[nt][mt] + bias[nt];
       if constexpr (EPI == OVG_EPI_GELU) {
-        v[0] = gelu_erf<T>(v[0]); v[1] = gelu_erf<T>(v[1]); v[2] = gelu_erf<T>(v[2]); v[3] = gelu_erf<T>(v[3]);
+        v[nt][0] = gelu_erf<T>(v[nt][0]); v[nt][1] = gelu_erf<T>(v[nt][1]); v[nt][2] = gelu_erf<T>(v[nt][2]); v[nt][3] = gelu_erf<T>(v[nt][3]);
       }
-      if constexpr (EPI == OVG_EPI_RES) {
-        const f32x4 r = *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldres + n);
-        const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + n);
-        v = r + gm * v;
-        if (inj) v += *reinterpret_cast<const f32x4*>(p.inject + (int64_t)(m / (int)p.inj_period) * N + n);
-      }
-      if constexpr (EPI == OVG_EPI_PATCH) { v += *reinterpret_cast<const f32x4*>(p.table + (int64_t)trow * N + n); }
-      if constexpr (OUT_F32 || EPI == OVG_EPI_RES || EPI == OVG_EPI_PATCH) {
-        *reinterpret_cast<f32x4*>(static_cast<float*>(p.y) + orow * p.ldy + n) = v;
-      } else {
-        store4<T>(static_cast<T*>(p.y) + orow * p.ldy + n, v[0], v[1], v[2], v[3]);
+      if constexpr (EPI == OVG_EPI_RES) v[nt] = ex_cur[nt] + gam[nt] * v[nt];
+      if constexpr (EPI == OVG_EPI_RES && INJECT) v[nt] += on_cur * inj_cur[nt];
+      if constexpr (EPI == OVG_EPI_PATCH) v[nt] += ex_cur[nt];
+    }
+    const int64_t orow = kRowLoads ? orow_cur : (int64_t)(m_w0 + mt * 16 + lr);
+    if (ok) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        if constexpr (OUT_F32 || EPI == OVG_EPI_RES || EPI == OVG_EPI_PATCH) {
+          *reinterpret_cast<f32x4*>(static_cast<float*>(p.y) + orow * p.ldy + ncol + nt * 16) = v[nt];
+        } else {
+          store4<T>(static_cast<T*>(p.y) + orow * p.ldy + ncol + nt * 16, v[nt][0], v[nt][1], v[nt][2], v[nt][3]);
+        }
       }
     }
+    if (kRowLoads && mt + 1 < MT) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) { ex_cur[nt] = ex_nxt[nt]; inj_cur[nt] = inj_nxt[nt]; }
+      on_cur = on_nxt; orow_cur = orow_nxt;
+    }
   }
+}
+
+template <typename T, int EPI, bool OUT_F32, int MT>
+OVG_DEV void linear_epilogue(const ovg_linear_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int n_w0) {
+  if constexpr (EPI == OVG_EPI_RES) {
+    if (p.inject != nullptr) { linear_epilogue_impl<T, EPI, OUT_F32, MT, true>(p, acc, m_w0, n_w0); return; }
+  }
+  linear_epilogue_impl<T, EPI, OUT_F32, MT, false>(p, acc, m_w0, n_w0);
 }
 
 template <typename T, int EPI, bool OUT_F32>
@@ -197,8 +259,85 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(ovg_linear_params p, int
 // QKV epilogue on a wave's 64(n) x 16*MT(m) block (64 columns = one head of q, k or v):
 // bias + per-head LayerNorm(64) + 2-D RoPE + q scale, head-major stores, V transposed
 // ---------------------------------------------------------------------------
+// Same discipline as linear_epilogue: everything that is uniform over the wave's rows (bias, q/k-norm affine rows,
+// which of q / k / v this wave holds, whether norm / RoPE apply) is decided or loaded ONCE and the row loops are
+// branch-free up to the predicated store. The RoPE cos / sin table (<= 128 positions x 16 frequencies, 16 KB) is
+// copied into LDS when the kernel starts and read from there (first version: four dependent global loads per row
+// block, one exposed L2 round trip each time, ~10 us per 256 x 256 tile).
+template <typename T, int MT, bool NORM, bool ROPE>
+OVG_DEV void qk_rows(const f32x4 (&acc)[4][MT], const float (&bias)[16], const float* __restrict__ nw_p, const float* __restrict__ nb_p,
+                     const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, T* __restrict__ out, const int64_t npad,
+                     const int m_w0, const int M, const int seq, const int h, const int tokens_per_view, const int n_special,
+                     const int grid_w, const float qk_eps, const float scale) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
+  float nw[16], nb[16];
+  if constexpr (NORM) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(nw_p + nt * 16 + 4 * g);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(nb_p + nt * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { nw[nt * 4 + r] = a[r]; nb[nt * 4 + r] = b[r]; }
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m_w0 + mt * 16 + lr;
+    const bool valid = m < M;
+    const int mm = valid ? m : M - 1;
+    const int bidx = mm / seq, n = mm - bidx * seq;
+    f32x4 cy, sy, cx, sxn;
+    if constexpr (ROPE) {
+      const int t = mm % tokens_per_view;
+      const int pp = t - n_special;
+      const int py = pp >= 0 ? pp / grid_w + 1 : 0, px = pp >= 0 ? pp % grid_w + 1 : 0;
+      cy = *reinterpret_cast<const f32x4*>(rope_cos + py * 16 + 4 * g);
+      sy = *reinterpret_cast<const f32x4*>(rope_sin + py * 16 + 4 * g);
+      cx = *reinterpret_cast<const f32x4*>(rope_cos + px * 16 + 4 * g);
+      sxn = *reinterpret_cast<const f32x4*>(rope_sin + px * 16 + 4 * g);
+    }
+    float v[16];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[nt][mt][r] + bias[nt * 4 + r];
+    if constexpr (NORM) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s += v[i];
+      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+      const float mean = s * (1.0f / 64.0f);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float d = v[i] - mean; q += d * d; }
+      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+      const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + qk_eps);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = (v[i] - mean) * rstd * nw[i] + nb[i];
+    }
+    if constexpr (ROPE) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a0 = v[r], a1 = v[4 + r];          // features j, j+16 of the y half
+        v[r] = a0 * cy[r] - a1 * sy[r];
+        v[4 + r] = a1 * cy[r] + a0 * sy[r];
+        const float b0 = v[8 + r], b1 = v[12 + r];     // features j, j+16 of the x half
+        v[8 + r] = b0 * cx[r] - b1 * sxn[r];
+        v[12 + r] = b1 * cx[r] + b0 * sxn[r];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] *= scale;          // 1.0 for k (exact), q_scale for q
+    if (valid) {
+      T* dst = out + (((int64_t)bidx * OVG_H + h) * npad + n) * OVG_D + 4 * g;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) store4<T>(dst + nt * 16, v[nt * 4], v[nt * 4 + 1], v[nt * 4 + 2], v[nt * 4 + 3]);
+    }
+  }
+}
+
 template <typename T, int MT>
-OVG_DEV void qkv_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int ncol0_) {
+OVG_DEV void qk_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int ncol0_, const float* rope_tab) {
   const int ncol0 = __builtin_amdgcn_readfirstlane(ncol0_);   // wave-uniform: keep the q/k/v dispatch scalar
   const int M = (int)p.M;
   const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
@@ -212,97 +351,103 @@ OVG_DEV void qkv_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], co
     const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + ncol0 + nt * 16 + 4 * g);
     bias[nt * 4 + 0] = b[0]; bias[nt * 4 + 1] = b[1]; bias[nt * 4 + 2] = b[2]; bias[nt * 4 + 3] = b[3];
   }
-  float nw[16], nb[16];
-  const bool do_norm = p.qk_norm && which < 2;
-  if (do_norm) {
-    const float* w_ = which == 0 ? p.qn_w : p.kn_w;
-    const float* b_ = which == 0 ? p.qn_b : p.kn_b;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(w_ + nt * 16 + 4 * g);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(b_ + nt * 16 + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { nw[nt * 4 + r] = a[r]; nb[nt * 4 + r] = b[r]; }
-    }
+  {
+    const float* nw_p = which == 0 ? p.qn_w : p.kn_w;
+    const float* nb_p = which == 0 ? p.qn_b : p.kn_b;
+    T* out = static_cast<T*>(which == 0 ? p.q : p.k);
+    const int64_t npad = which == 0 ? p.nq_pad : p.nk_pad;
+    const float scale = which == 0 ? p.q_scale : 1.0f;
+    const int tpv = (int)p.tokens_per_view;
+#define OVG_QK_ROWS(NORM, ROPE) qk_rows<T, MT, NORM, ROPE>(acc, bias, nw_p, nb_p, rope_tab, rope_tab + 128 * 16, out, npad, m_w0, M, seq, h, \
+                                                             tpv, p.n_special, p.grid_w, p.qk_eps, scale)
+    if (p.qk_norm) { if (p.rope) OVG_QK_ROWS(true, true); else OVG_QK_ROWS(true, false); }
+    else { if (p.rope) OVG_QK_ROWS(false, true); else OVG_QK_ROWS(false, false); }
+#undef OVG_QK_ROWS
   }
+}
 
+// V^T tiles: the main loop ran with SWAP, so acc[nt][mt][r] = V[token m = m_w0 + 16 mt + 4g + r][feature d = 16 nt + (lane & 15)]:
+// four consecutive tokens of one feature per register group = ONE 8-byte store into V^T [B*H, 64, nk_pad] (the first
+// version held 4 features of one token and issued 16 two-byte stores per row block, each block fenced by a vmcnt(0)).
+template <typename T, int MT>
+OVG_DEV void v_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int ncol0_) {
+  const int ncol0 = __builtin_amdgcn_readfirstlane(ncol0_);
+  const int M = (int)p.M, seq = (int)p.seq;
+  const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
+  const int h = (ncol0 % OVG_C) / OVG_D;
+  float bias[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) bias[nt] = p.bias[ncol0 + nt * 16 + lr];
+  T* vt = static_cast<T*>(p.vt);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int m = m_w0 + mt * 16 + lr;
-    const bool valid = m < M;
-    float v[16];
+    const int m = m_w0 + mt * 16 + 4 * g;               // first of this lane's 4 tokens
+    const int mc = m < M ? m : M - 1;
+    const int bidx = mc / seq, n = mc - bidx * seq;
+    // all four tokens valid and in the same sequence, and the vector store naturally aligned to its element group: the 8-byte
+    // store of the 16-bit modes needs n even (true at 518^2: m % 4 == 0 and 1374 is even; odd token counts take the scalar
+    // path on every other view), the 16-byte store of the f32 mode needs n % 4 == 0
+    const bool whole = (m + 3 < M) && (n + 3 < seq) && ((n & (sizeof(T) == 2 ? 1 : 3)) == 0);
+    T* row0 = vt + (((int64_t)bidx * OVG_H + h) * OVG_D + lr) * p.nk_pad + n;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[nt][mt][r] + bias[nt * 4 + r];
-
-    const int mm = valid ? m : M - 1;
-    const int bidx = mm / seq, n = mm % seq;
-    if (which < 2) {
-      if (do_norm) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s += v[i];
-        s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-        const float mean = s * (1.0f / 64.0f);
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { const float d = v[i] - mean; q += d * d; }
-        q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-        const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + p.qk_eps);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = (v[i] - mean) * rstd * nw[i] + nb[i];
-      }
-      if (p.rope) {
-        const int t = mm % (int)p.tokens_per_view;
-        int py = 0, px = 0;
-        if (t >= p.n_special) { const int pp = t - p.n_special; py = pp / p.grid_w + 1; px = pp % p.grid_w + 1; }
-        const f32x4 cy = *reinterpret_cast<const f32x4*>(p.rope_cos + py * 16 + 4 * g);
-        const f32x4 sy = *reinterpret_cast<const f32x4*>(p.rope_sin + py * 16 + 4 * g);
-        const f32x4 cx = *reinterpret_cast<const f32x4*>(p.rope_cos + px * 16 + 4 * g);
-        const f32x4 sxn = *reinterpret_cast<const f32x4*>(p.rope_sin + px * 16 + 4 * g);
+    for (int nt = 0; nt < 4; ++nt) {
+      const f32x4 v = acc[nt][mt] + bias[nt];
+      T* dst = row0 + (int64_t)nt * 16 * p.nk_pad;
+      if (whole) {
+        store4<T>(dst, v[0], v[1], v[2], v[3]);
+      } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float a0 = v[r], a1 = v[4 + r];          // features j, j+16 of the y half
-          v[r] = a0 * cy[r] - a1 * sy[r];
-          v[4 + r] = a1 * cy[r] + a0 * sy[r];
-          const float b0 = v[8 + r], b1 = v[12 + r];     // features j, j+16 of the x half
-          v[8 + r] = b0 * cx[r] - b1 * sxn[r];
-          v[12 + r] = b1 * cx[r] + b0 * sxn[r];
+          const int mr = m + r;
+          if (mr < M) {
+            const int br = mr / seq, nr = mr - br * seq;
+            vt[(((int64_t)br * OVG_H + h) * OVG_D + nt * 16 + lr) * p.nk_pad + nr] = TT<T>::from_f32(v[r]);
+          }
         }
       }
-      if (which == 0) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] *= p.q_scale;
-      }
-      if (valid) {
-        const int64_t npad = which == 0 ? p.nq_pad : p.nk_pad;
-        T* dst = static_cast<T*>(which == 0 ? p.q : p.k) + (((int64_t)bidx * OVG_H + h) * npad + n) * OVG_D + 4 * g;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) store4<T>(dst + nt * 16, v[nt * 4], v[nt * 4 + 1], v[nt * 4 + 2], v[nt * 4 + 3]);
-      }
-    } else if (valid) {
-      T* dst = static_cast<T*>(p.vt) + ((int64_t)bidx * OVG_H + h) * OVG_D * p.nk_pad + n;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dst[(int64_t)(nt * 16 + 4 * g + r) * p.nk_pad] = TT<T>::from_f32(v[nt * 4 + r]);
     }
   }
 }
 
+// RoPE table -> LDS by LDS-DMA (no VGPR round trip, nothing waits for it: it lands long before the epilogue, and being
+// issued BEFORE the main loop's stage DMAs it never disturbs their counted vmcnt waits). Layout: cos rows at [0, 8 KB),
+// sin rows at [8 KB, 16 KB), 64 B per position; positions >= max_pos are filled with a clamped (valid) source address.
+OVG_DEV void stage_rope_table(const ovg_qkv_params& p, unsigned char* tab, int nwaves) {
+  if (!p.rope) return;
+  typedef __attribute__((address_space(1))) const void* gp_t;
+  typedef __attribute__((address_space(3))) void* lp_t;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bytes = p.max_pos * 64;
+  for (int i = wave; i < 16; i += nwaves) {               // 16 pieces of 1 KB: 8 of cos, 8 of sin
+    const int piece = i & 7;
+    int off = piece * 1024 + lane * 16;
+    off = off < bytes ? off : bytes - 16;
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(i < 8 ? p.rope_cos : p.rope_sin) + off;
+    __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)(tab + i * 1024), 16, 0, 0);
+  }
+}
+constexpr int ROPE_LDS_BYTES = 2 * 128 * 16 * 4;          // max_pos <= 128 (ovg_qkv checks)
+
 template <typename T>
 __global__ __launch_bounds__(256, 2) void qkv_kernel(ovg_qkv_params p, int nt_begin, int nt_count) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128 + ROPE_LDS_BYTES];
   constexpr int N = 3 * OVG_C, K = OVG_C;
   const int M = (int)p.M;
   int tm, tn;
   tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + BM - 1) / BM, nt_count, tm, tn);   // nt_count carries GM in its high half
   const int m0 = tm * BM, n0 = (nt_begin + tn) * BN;
-  f32x4 acc[4][4];
-  gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
   const int wave = threadIdx.x >> 6;
-  qkv_epilogue<T, 4>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64);
+  f32x4 acc[4][4];
+  if (n0 >= 2 * OVG_C) {                                   // V^T tile (workgroup-uniform): transposed accumulators
+    gemm_mainloop<T, true>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
+    v_epilogue<T, 4>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64);
+  } else {
+    float* rope_tab = reinterpret_cast<float*>(lds + 2 * 128 * 128);
+    stage_rope_table(p, lds + 2 * 128 * 128, 4);           // waited for and made visible by the main loop's __syncthreads
+    gemm_mainloop<T, false>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
+    qk_epilogue<T, 4>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64, rope_tab);
+  }
 }
 
 #include "ovg_gemm256.h"
@@ -323,21 +468,28 @@ __global__ __launch_bounds__(512) void linear256_kernel(ovg_linear_params p, int
 
 template <typename T>
 __global__ __launch_bounds__(512) void qkv256_kernel(ovg_qkv_params p, int nt_begin, int nt_count) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds256[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds256[];   // ring (g256::LDS_BYTES) + RoPE table (ROPE_LDS_BYTES)
   constexpr int N = 3 * OVG_C, K = OVG_C;
   const int M = (int)p.M;
   int tm, tn;
   tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + g256::BM2 - 1) / g256::BM2, nt_count, tm, tn);
   const int m0 = tm * g256::BM2, n0 = (nt_begin + tn) * g256::BN2;
-  f32x4 acc[4][8];
-  g256::mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds256, acc);
   const int wave = threadIdx.x >> 6;
-  qkv_epilogue<T, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64);
+  f32x4 acc[4][8];
+  if (n0 >= 2 * OVG_C) {                                   // V^T tile (workgroup-uniform): transposed accumulators
+    g256::mainloop<T, true>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds256, acc);
+    v_epilogue<T, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64);
+  } else {
+    float* rope_tab = reinterpret_cast<float*>(lds256 + g256::LDS_BYTES);
+    stage_rope_table(p, lds256 + g256::LDS_BYTES, 8);      // older than every stage DMA: retired by the loop's first counted wait, visible after its barriers
+    g256::mainloop<T, false>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds256, acc);
+    qk_epilogue<T, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, rope_tab);
+  }
 }
 
 template <typename KernelT>
-int allow_big_lds(KernelT kernel) {     // once per kernel: opt in to > 64 KB of dynamic LDS
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, g256::LDS_BYTES) == hipSuccess ? OVG_OK : OVG_E_LAUNCH;
+int allow_big_lds(KernelT kernel, int bytes = g256::LDS_BYTES) {     // once per kernel: opt in to > 64 KB of dynamic LDS
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? OVG_OK : OVG_E_LAUNCH;
 }
 
 // tile-order group sizes (m-tiles per group, tile_coords): measured in profiles/r01_gemm_tile_order_ab.txt / r01_gemm256_ab.txt
@@ -457,6 +609,7 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
     if (!p->rope_cos || !p->rope_sin || p->tokens_per_view <= 0 || p->grid_w <= 0) return OVG_E_ARG;
     const int64_t np = p->tokens_per_view - p->n_special;
     if (np <= 0 || (np - 1) / p->grid_w + 1 >= p->max_pos || p->grid_w >= p->max_pos) return OVG_E_ARG;
+    if (p->max_pos > 128 || !aligned16(p->rope_cos) || !aligned16(p->rope_sin)) return OVG_E_ARG;   // the table is staged in 16 KB of LDS
   }
   if (p->part < 0 || p->part > 2) return OVG_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -469,13 +622,13 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
     const dim3 grid2((unsigned)(((p->M + g256::BM2 - 1) / g256::BM2) * ntc));
     const int ntg2 = ntc | (TILE_GROUP256 << 16);
     if (p->dtype == OVG_BF16) {
-      static const int ok = allow_big_lds(qkv256_kernel<bf16_t>);
+      static const int ok = allow_big_lds(qkv256_kernel<bf16_t>, g256::LDS_BYTES + ROPE_LDS_BYTES);
       if (ok != OVG_OK) return ok;
-      OVG_LAUNCH((qkv256_kernel<bf16_t>), grid2, dim3(512), g256::LDS_BYTES, st, *p, ntb, ntg2);
+      OVG_LAUNCH((qkv256_kernel<bf16_t>), grid2, dim3(512), g256::LDS_BYTES + ROPE_LDS_BYTES, st, *p, ntb, ntg2);
     } else {
-      static const int ok = allow_big_lds(qkv256_kernel<f16_t>);
+      static const int ok = allow_big_lds(qkv256_kernel<f16_t>, g256::LDS_BYTES + ROPE_LDS_BYTES);
       if (ok != OVG_OK) return ok;
-      OVG_LAUNCH((qkv256_kernel<f16_t>), grid2, dim3(512), g256::LDS_BYTES, st, *p, ntb, ntg2);
+      OVG_LAUNCH((qkv256_kernel<f16_t>), grid2, dim3(512), g256::LDS_BYTES + ROPE_LDS_BYTES, st, *p, ntb, ntg2);
     }
     OVG_CHECK_LAUNCH();
     return OVG_OK;

@@ -48,8 +48,10 @@ OVG_DEV void wait_tiles_in_flight(int n) {     // leave at most n k-stages (4 DM
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// leaves acc[nt][mt] = C[n = n0 + 64 wn + 16 nt + 4g + r][m = m0 + 128 wm + 16 mt + (lane & 15)]
-template <typename T>
+// leaves acc[nt][mt] = C[n = n0 + 64 wn + 16 nt + 4g + r][m = m0 + 128 wm + 16 mt + (lane & 15)]; with SWAP the MFMA
+// operands trade places and every 16 x 16 block comes out transposed: acc[nt][mt][r] = C[n = .. + 16 nt + (lane & 15)][m = .. + 16 mt + 4g + r]
+// (the V^T tiles of the QKV projection: a lane then owns 4 CONSECUTIVE tokens of one feature = one 8-byte store)
+template <typename T, bool SWAP = false>
 OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict__ W, int64_t ldw,
                       int M, int N, int K, int m0, int n0, unsigned char* lds, f32x4 (&acc)[4][8]) {
   static_assert(sizeof(T) == 2, "16-bit operands");
@@ -100,7 +102,10 @@ OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict_
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int mt = 0; mt < 8; ++mt) TT<T>::mma(acc[nt][mt], a[nt], b[mt]);
+      for (int mt = 0; mt < 8; ++mt) {
+        if constexpr (SWAP) TT<T>::mma(acc[nt][mt], b[mt], a[nt]);
+        else TT<T>::mma(acc[nt][mt], a[nt], b[mt]);
+      }
     __builtin_amdgcn_s_setprio(0);
   };
   auto in_flight_after = [&](int t) {   // k-stages issued beyond tile t when the wave has staged up to tile min(t + 2, nk - 1)
@@ -143,5 +148,6 @@ OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict_
     }
   }
 }
+
 
 }  // namespace g256
