@@ -82,6 +82,33 @@ template <int RB> OVG_DEV int swz_off(int row, int chunk) {
   else return row * 256 + ((chunk ^ (row & 15)) << 4);
 }
 
+// x / d and x % d for 0 <= x < 2^24, 1 <= d: one v_rcp_f32 per divisor (hoisted by the caller), then ~8 VALU per
+// division instead of the ~30 of the generic 32-bit sequence hipcc expands (the epilogues divide token indices by the
+// sequence length / tokens per view / patch-grid width once per 16-row block: r02 profile of the QKV kernel showed
+// 790 v_mul_lo_u32 + 730 v_cndmask_b32 of division code against 256 MFMAs).
+struct FastDiv {
+  int d; float rd;
+  OVG_DEV explicit FastDiv(int d_) : d(d_), rd(__builtin_amdgcn_rcpf((float)d_)) {}
+  OVG_DEV void divmod(int x, int& q, int& r) const {
+    q = (int)((float)x * rd);                  // off by at most one either way
+    r = x - q * d;
+    if (r < 0) { r += d; --q; }
+    if (r >= d) { r -= d; ++q; }
+  }
+};
+
+// sum over the 4 lanes {l, l^16, l^32, l^48} with the gfx950 swap instructions (no LDS crossbar, see ovg_attn16.h)
+OVG_DEV float quad16_sum(float v) {
+  unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  unsigned a = r[0], b = r[1];
+  const float s = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+  u = __builtin_bit_cast(unsigned, s);
+  r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  a = r[0]; b = r[1];
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+
 OVG_DEV float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

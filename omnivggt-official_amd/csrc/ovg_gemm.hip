@@ -170,6 +170,10 @@ OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)
   // output may alias the residual (fc2 runs in place), so the compiler may not move a later block's loads above an
   // earlier block's stores on its own; different row blocks never touch the same rows, so doing it by hand is safe.
   constexpr bool kRowLoads = (EPI == OVG_EPI_RES || EPI == OVG_EPI_PATCH);
+  // one-ahead prefetch only in the 256 x 256 kernels (1 workgroup per CU: nobody else hides the latency); the 128 x 128
+  // kernels run 3 workgroups per CU at <= 168 VGPRs and must not grow past that
+  constexpr bool kAhead = kRowLoads && MT == 8;
+  const FastDiv div_p0(EPI == OVG_EPI_PATCH ? (int)p.p0 : 1), div_per(INJECT ? (int)p.inj_period : 1);
   f32x4 ex_cur[4], ex_nxt[4], inj_cur[4], inj_nxt[4];
   float on_cur = 0.f, on_nxt = 0.f;
   int64_t orow_cur = 0, orow_nxt = 0;
@@ -178,7 +182,8 @@ OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)
     const int mc = m < M ? m : M - 1;                  // loads of dead rows read a live row instead of branching
     orow = mc;
     if constexpr (EPI == OVG_EPI_PATCH) {
-      const int vw = mc / (int)p.p0, t = mc - vw * (int)p.p0;
+      int vw, t;
+      div_p0.divmod(mc, vw, t);
       orow = (int64_t)vw * p.p1 + p.row_off + t;
       const float* trow = p.table + (int64_t)(t + 1) * N + ncol;
 #pragma unroll
@@ -191,18 +196,20 @@ OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)
       if constexpr (INJECT) {
         // camera-token injection (omnivggt_aggregator.py:284-301) on rows m % period == 0: every lane reads ITS view's
         // row (an L1 / L2 hit: 1 row per 1374) and scales it by 0 or 1 -- no divergent branch in the row loop
-        const int per = (int)p.inj_period, vw = mc / per;
-        on = (mc - vw * per == 0) ? 1.0f : 0.0f;
+        int vw, rem;
+        div_per.divmod(mc, vw, rem);
+        on = rem == 0 ? 1.0f : 0.0f;
         const float* irow = p.inject + (int64_t)vw * N + ncol;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) inj[nt] = *reinterpret_cast<const f32x4*>(irow + nt * 16);
       }
     }
   };
-  fetch(0, ex_cur, inj_cur, on_cur, orow_cur);
+  if (kAhead) fetch(0, ex_cur, inj_cur, on_cur, orow_cur);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    if (kRowLoads && mt + 1 < MT) fetch(mt + 1, ex_nxt, inj_nxt, on_nxt, orow_nxt);
+    if (kAhead) { if (mt + 1 < MT) fetch(mt + 1, ex_nxt, inj_nxt, on_nxt, orow_nxt); }
+    else if (kRowLoads) fetch(mt, ex_cur, inj_cur, on_cur, orow_cur);
     const bool ok = (m_w0 + mt * 16 + lr) < M;
     f32x4 v[4];
 #pragma unroll
@@ -226,7 +233,7 @@ OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)
         }
       }
     }
-    if (kRowLoads && mt + 1 < MT) {
+    if (kAhead && mt + 1 < MT) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) { ex_cur[nt] = ex_nxt[nt]; inj_cur[nt] = inj_nxt[nt]; }
       on_cur = on_nxt; orow_cur = orow_nxt;
@@ -270,6 +277,7 @@ OVG_DEV void qk_rows(const f32x4 (&acc)[4][MT], const float (&bias)[16], const f
                      const int m_w0, const int M, const int seq, const int h, const int tokens_per_view, const int n_special,
                      const int grid_w, const float qk_eps, const float scale) {
   const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
+  const FastDiv div_seq(seq), div_tpv(ROPE ? tokens_per_view : 1), div_gw(ROPE ? grid_w : 1);
   float nw[16], nb[16];
   if constexpr (NORM) {
 #pragma unroll
@@ -285,12 +293,16 @@ OVG_DEV void qk_rows(const f32x4 (&acc)[4][MT], const float (&bias)[16], const f
     const int m = m_w0 + mt * 16 + lr;
     const bool valid = m < M;
     const int mm = valid ? m : M - 1;
-    const int bidx = mm / seq, n = mm - bidx * seq;
+    int bidx, n;
+    div_seq.divmod(mm, bidx, n);
     f32x4 cy, sy, cx, sxn;
     if constexpr (ROPE) {
-      const int t = mm % tokens_per_view;
+      int vw, t, py, px;
+      div_tpv.divmod(mm, vw, t);
       const int pp = t - n_special;
-      const int py = pp >= 0 ? pp / grid_w + 1 : 0, px = pp >= 0 ? pp % grid_w + 1 : 0;
+      div_gw.divmod(pp >= 0 ? pp : 0, py, px);
+      py = pp >= 0 ? py + 1 : 0;
+      px = pp >= 0 ? px + 1 : 0;
       cy = *reinterpret_cast<const f32x4*>(rope_cos + py * 16 + 4 * g);
       sy = *reinterpret_cast<const f32x4*>(rope_sin + py * 16 + 4 * g);
       cx = *reinterpret_cast<const f32x4*>(rope_cos + px * 16 + 4 * g);
@@ -305,13 +317,15 @@ OVG_DEV void qk_rows(const f32x4 (&acc)[4][MT], const float (&bias)[16], const f
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) s += v[i];
-      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+      s = quad16_sum(s);
       const float mean = s * (1.0f / 64.0f);
       float q = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { const float d = v[i] - mean; q += d * d; }
-      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-      const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + qk_eps);
+      q = quad16_sum(q);
+      float rstd;
+      if constexpr (sizeof(T) == 4) rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + qk_eps);     // parity mode: IEEE sqrt + divide
+      else rstd = __builtin_amdgcn_rsqf(q * (1.0f / 64.0f) + qk_eps);                     // 1 ulp, far below bf16 / f16 resolution
 #pragma unroll
       for (int i = 0; i < 16; ++i) v[i] = (v[i] - mean) * rstd * nw[i] + nb[i];
     }
@@ -337,12 +351,13 @@ OVG_DEV void qk_rows(const f32x4 (&acc)[4][MT], const float (&bias)[16], const f
 }
 
 template <typename T, int MT>
-OVG_DEV void qk_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int ncol0_, const float* rope_tab) {
+OVG_DEV void qk_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int ncol0_,
+                         const float* rope_c, const float* rope_s) {
   const int ncol0 = __builtin_amdgcn_readfirstlane(ncol0_);   // wave-uniform: keep the q/k/v dispatch scalar
   const int M = (int)p.M;
-  const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
+  const int lane = threadIdx.x & 63, g = lane >> 4;
   const int seq = (int)p.seq;
-  const int which = ncol0 / OVG_C;                      // 0 q, 1 k, 2 v (uniform per wave)
+  const int which = ncol0 / OVG_C;                      // 0 q, 1 k (uniform per wave; V^T tiles go through v_epilogue)
   const int h = (ncol0 % OVG_C) / OVG_D;                // head of this wave's 64 columns
 
   float bias[16];
@@ -358,7 +373,7 @@ OVG_DEV void qk_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], con
     const int64_t npad = which == 0 ? p.nq_pad : p.nk_pad;
     const float scale = which == 0 ? p.q_scale : 1.0f;
     const int tpv = (int)p.tokens_per_view;
-#define OVG_QK_ROWS(NORM, ROPE) qk_rows<T, MT, NORM, ROPE>(acc, bias, nw_p, nb_p, rope_tab, rope_tab + 128 * 16, out, npad, m_w0, M, seq, h, \
+#define OVG_QK_ROWS(NORM, ROPE) qk_rows<T, MT, NORM, ROPE>(acc, bias, nw_p, nb_p, rope_c, rope_s, out, npad, m_w0, M, seq, h, \
                                                              tpv, p.n_special, p.grid_w, p.qk_eps, scale)
     if (p.qk_norm) { if (p.rope) OVG_QK_ROWS(true, true); else OVG_QK_ROWS(true, false); }
     else { if (p.rope) OVG_QK_ROWS(false, true); else OVG_QK_ROWS(false, false); }
@@ -375,6 +390,7 @@ OVG_DEV void v_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], cons
   const int M = (int)p.M, seq = (int)p.seq;
   const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
   const int h = (ncol0 % OVG_C) / OVG_D;
+  const FastDiv div_seq(seq);
   float bias[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) bias[nt] = p.bias[ncol0 + nt * 16 + lr];
@@ -383,7 +399,8 @@ OVG_DEV void v_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], cons
   for (int mt = 0; mt < MT; ++mt) {
     const int m = m_w0 + mt * 16 + 4 * g;               // first of this lane's 4 tokens
     const int mc = m < M ? m : M - 1;
-    const int bidx = mc / seq, n = mc - bidx * seq;
+    int bidx, n;
+    div_seq.divmod(mc, bidx, n);
     // all four tokens valid and in the same sequence, and the vector store naturally aligned to its element group: the 8-byte
     // store of the 16-bit modes needs n even (true at 518^2: m % 4 == 0 and 1374 is even; odd token counts take the scalar
     // path on every other view), the 16-byte store of the f32 mode needs n % 4 == 0
@@ -400,7 +417,8 @@ OVG_DEV void v_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], cons
         for (int r = 0; r < 4; ++r) {
           const int mr = m + r;
           if (mr < M) {
-            const int br = mr / seq, nr = mr - br * seq;
+            int br, nr;
+            div_seq.divmod(mr, br, nr);
             vt[(((int64_t)br * OVG_H + h) * OVG_D + nt * 16 + lr) * p.nk_pad + nr] = TT<T>::from_f32(v[r]);
           }
         }
@@ -431,7 +449,7 @@ constexpr int ROPE_LDS_BYTES = 2 * 128 * 16 * 4;          // max_pos <= 128 (ovg
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void qkv_kernel(ovg_qkv_params p, int nt_begin, int nt_count) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128 + ROPE_LDS_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128];
   constexpr int N = 3 * OVG_C, K = OVG_C;
   const int M = (int)p.M;
   int tm, tn;
@@ -443,10 +461,10 @@ __global__ __launch_bounds__(256, 2) void qkv_kernel(ovg_qkv_params p, int nt_be
     gemm_mainloop<T, true>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
     v_epilogue<T, 4>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64);
   } else {
-    float* rope_tab = reinterpret_cast<float*>(lds + 2 * 128 * 128);
-    stage_rope_table(p, lds + 2 * 128 * 128, 4);           // waited for and made visible by the main loop's __syncthreads
+    // 3 workgroups per CU hide the RoPE-table round trips here: the table is read from global memory (L1 / L2 hits); staging it
+    // in LDS cost more than it saved on these small tiles (the DMA sits in front of the register-staged loop's first loads)
     gemm_mainloop<T, false>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
-    qk_epilogue<T, 4>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64, rope_tab);
+    qk_epilogue<T, 4>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64, p.rope_cos, p.rope_sin);
   }
 }
 
@@ -483,7 +501,7 @@ __global__ __launch_bounds__(512) void qkv256_kernel(ovg_qkv_params p, int nt_be
     float* rope_tab = reinterpret_cast<float*>(lds256 + g256::LDS_BYTES);
     stage_rope_table(p, lds256 + g256::LDS_BYTES, 8);      // older than every stage DMA: retired by the loop's first counted wait, visible after its barriers
     g256::mainloop<T, false>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds256, acc);
-    qk_epilogue<T, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, rope_tab);
+    qk_epilogue<T, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, rope_tab, rope_tab + 128 * 16);
   }
 }
 
