@@ -559,23 +559,21 @@ int launch_linear256(const ovg_linear_params& p, hipStream_t st) {
     default: return OVG_E_ARG;
   }
 }
-// Tile choice for the 16-bit modes (measured, tests/bench_kernels.py gemm, profiles/r01_gemm256_ab.txt): the 256 x 256
-// ping-pong loop wins by 9-14 % on QKV / fc1 / fc2 once its tiles fill the 256 CUs evenly, and loses on the proj GEMM
-// (K = 1024 with the f32 residual epilogue: one workgroup per CU cannot overlap that epilogue with another workgroup's
-// main loop) and on badly quantised grids (QKV at M = 10 992: 516 tiles = 2.02 rounds).
+// Tile choice for the 16-bit modes (measured: tests/bench_kernels.py gemm, profiles/r02_gemm_epilogue_mlp.txt): with the
+// r02 epilogues the 256 x 256 ping-pong loop wins on QKV / fc1 / fc2 at every token count of the benches (M = 10 992:
+// +7 / +13 / +19 %, M = 87 936: +28 / +5 / +17 %), also where its grid quantises badly (QKV at M = 10 992: 516 tiles = 2.02
+// rounds) or leaves CUs idle (fc2 at M = 10 992: 172 tiles); the proj GEMM (K = 1024, f32 residual epilogue, N = 1024) is a
+// tie at M = 87 936 and better on 128 x 128 below (3 workgroups per CU hide the residual round trips). Tiny problems
+// (fewer 256 x 256 tiles than half the CUs) stay on 128 x 128.
 // Returns 1 = use 256^2, 0 = use 128^2, -1 = the caller forced a tile this shape / dtype cannot run.
 int choose_256(int tile, bool sixteen_bit, int64_t M, int64_t N, int64_t K, bool light_epilogue_or_long_k) {
   const bool legal = sixteen_bit && N % g256::BN2 == 0 && K % 32 == 0;
   if (tile == OVG_TILE_128) return 0;
   if (tile == OVG_TILE_256) return legal ? 1 : -1;
   if (tile != OVG_TILE_AUTO) return -1;
-  if (!legal) return 0;
-  // in situ (bench.py, whole forward) the 256^2 kernels only pay off for long token slices: at M = 10 992 the
-  // forward is 2 % faster with 128^2 everywhere, at M = 87 936 it is 2 % faster with this choice
-  if (!light_epilogue_or_long_k || M < 32768) return 0;
+  if (!legal || !light_epilogue_or_long_k) return 0;
   const int64_t tiles = ((M + g256::BM2 - 1) / g256::BM2) * (N / g256::BN2);
-  const int64_t rounds = (tiles + 255) / 256;
-  return (tiles * 100 >= rounds * 256 * 80 || K >= 2048) ? 1 : 0;   // >= 80 % of the last round's CUs busy
+  return tiles >= 128 ? 1 : 0;
 }
 
 template <typename T>
