@@ -267,14 +267,14 @@ int launch_attn(const ovg_attn_params& p, hipStream_t st) {
   return OVG_OK;
 }
 
-template <typename T, int QB, int WAVES, int MODE>
+template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false>
 int launch_attn16(const ovg_attn_params& p, hipStream_t st) {
   constexpr int BQ = 16 * QB * WAVES;
   const int nqt = (int)((p.nq + BQ - 1) / BQ);
   int total = 0;
   for (int i = 0; i < p.nseg; ++i) total += (int)((p.seg[i].nk + BC - 1) / BC);
   const dim3 grid((unsigned)(p.BH * nqt)), block(64 * WAVES);
-  OVG_LAUNCH((attn16_kernel<T, QB, WAVES, MODE>), grid, block, 0, st, p, nqt, total);
+  OVG_LAUNCH((attn16_kernel<T, QB, WAVES, MODE, OCC, VSUM>), grid, block, 0, st, p, nqt, total);
   OVG_CHECK_LAUNCH();
   return OVG_OK;
 }
@@ -301,6 +301,10 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
     case 25: return launch_attn16<T, 2, 4, 0>(p, st);
     case 18: return launch_attn16<T, 4, 4, 2>(p, st);
     case 19: return launch_attn16<T, 2, 4, 2>(p, st);
+    // r02 experiments (tests/bench_kernels.py attn; results in profiles/r02_attention_variants_ab.txt)
+    case 31: return launch_attn16<T, 4, 4, 0, 2, true>(p, st);    // row sums on the VALU instead of the ones-MFMA
+    case 32: return launch_attn16<T, 2, 8, 0, 4>(p, st);          // 8 waves x 32 rows, <= 128 VGPRs: 2 workgroups = 4 waves per SIMD
+    case 33: return launch_attn16<T, 4, 8, 0, 2>(p, st);          // 8 waves x 64 rows = 512-row q tiles, 1 workgroup per CU
     default: return OVG_E_ARG;
   }
 }

@@ -100,7 +100,7 @@ OVG_DEV u32x4 pack2(const f32x4 a, const f32x4 b) {
 // One pass over all key tiles of all segments for the wave's QB x 16 query rows; leaves the un-normalised
 // O^T in o, the row sums in lacc (every register of lacc[qb] holds the full sum of row q0 + 16 qb + lane&15) and the
 // negated reference maximum in negm (P = exp2(s + negm)): log2 sum_k exp2(s) = log2(lacc) - negm.
-template <typename T, int QB, int WAVES, int SM>
+template <typename T, int QB, int WAVES, int SM, bool VSUM = false>   // VSUM: row sums on the VALU (experiment, variant 31) instead of the ones-MFMA
 OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int bh, const int q0, const int total_tiles,
                        f32x4 (&o)[QB][4], f32x4 (&lacc)[QB], f32x4 (&negm)[QB]) {
   constexpr int NT = 64 * WAVES;
@@ -236,7 +236,8 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       pf[qb] = pack2<T>(sa[qb], sb[qb]);
-      lacc[qb] = mma_c<T>(ones, pf[qb], lacc[qb]);
+      if constexpr (VSUM) lacc[qb] += sa[qb] + sb[qb];   // lane-partial sums (4 registers x 4 lanes per row), reduced once after the loop
+      else lacc[qb] = mma_c<T>(ones, pf[qb], lacc[qb]);
     }
     const int voff = ((4 * u + g) ^ sx) << 4;
 #pragma unroll
@@ -303,13 +304,20 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
     __syncthreads();
     buf ^= 1;
   }
+  if constexpr (VSUM) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const float t = quad16_sum(lacc[qb][0] + lacc[qb][1] + lacc[qb][2] + lacc[qb][3]);
+      lacc[qb] = f32x4{t, t, t, t};
+    }
+  }
 }
 
 }  // namespace attn16
 
 // MODE: 0 = speculative anchored softmax + verified fallback, 1 = lazy-rescale only, 2 = forced fallback (tests)
-template <typename T, int QB, int WAVES, int MODE>
-__global__ __launch_bounds__(64 * WAVES, 2) void attn16_kernel(ovg_attn_params p, int nqt, int total_tiles) {
+template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false>   // OCC: minimum waves per SIMD the register allocation must allow
+__global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params p, int nqt, int total_tiles) {
   static_assert(sizeof(T) == 2, "16-bit types only");
   constexpr int RB = 128, KT_B = BC * RB, VT_B = OVG_D * RB, BQ = 16 * QB * WAVES;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (KT_B + VT_B)];
@@ -323,9 +331,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn16_kernel(ovg_attn_params p
 
   f32x4 o[QB][4], lacc[QB], negm[QB];
   if constexpr (MODE == 1) {
-    attn16::run_tiles<T, QB, WAVES, 0>(p, lds, bh, q0, total_tiles, o, lacc, negm);
+    attn16::run_tiles<T, QB, WAVES, 0, VSUM>(p, lds, bh, q0, total_tiles, o, lacc, negm);
   } else {
-    attn16::run_tiles<T, QB, WAVES, 2>(p, lds, bh, q0, total_tiles, o, lacc, negm);
+    attn16::run_tiles<T, QB, WAVES, 2, VSUM>(p, lds, bh, q0, total_tiles, o, lacc, negm);
     bool bad = MODE == 2;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn16_kernel(ovg_attn_params p
 #pragma unroll
         for (int r = 0; r < 4; ++r) bad = bad || attn16::nonfinite(o[qb][dt][r]);
     }
-    if (__syncthreads_or(bad ? 1 : 0)) attn16::run_tiles<T, QB, WAVES, 0>(p, lds, bh, q0, total_tiles, o, lacc, negm);
+    if (__syncthreads_or(bad ? 1 : 0)) attn16::run_tiles<T, QB, WAVES, 0, VSUM>(p, lds, bh, q0, total_tiles, o, lacc, negm);
   }
 
   const int bq = bh / OVG_H, hh = bh % OVG_H;

@@ -204,3 +204,30 @@ def test_from_safetensors_roundtrip(tmp_path):
     assert set(got) == set(sd)
     assert all(torch.equal(got[k], sd[k]) for k in sd)
     assert not m.training
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/omnivggt"), reason="needs the reference tree (build container only)")
+def test_integration_path_a_state_dict_swap_into_the_reference_model():
+    """INTEGRATION.md path A, executed: the REFERENCE OmniVGGT (reference heads, reference key names) gets this repo's
+    aggregator by load_state_dict(strict=True) + attribute swap; the swapped model keeps the reference's full key set and
+    the aggregator keeps the reference's forward signature."""
+    import inspect
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_shim
+    ref = ref_shim.build_reference_model()
+    ref_keys = set(ref.state_dict())
+    assert len(ref_keys) == 1505
+    hip = ZeroAggregator(pose_hidden_dim=9, compute_dtype=torch.bfloat16)
+    missing = hip.load_state_dict(ref.aggregator.state_dict(), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert len(hip.state_dict()) == len(ref.aggregator.state_dict()) == 1312
+    for k, v in ref.aggregator.state_dict().items():
+        assert torch.equal(hip.state_dict()[k], v)
+    ref_sig = list(inspect.signature(ref.aggregator.forward).parameters)
+    assert list(inspect.signature(hip.forward).parameters) == ref_sig
+    ref.aggregator = hip
+    assert set(ref.state_dict()) == ref_keys                     # checkpoint contract of the swapped model unchanged
+    with pytest.raises(L.OvgError):                              # and it fails loudly without a HIP device (no silent CPU path)
+        ref(torch.zeros(1, 2, 3, 518, 518), torch.zeros(1, 2, 3, 4), torch.zeros(1, 2, 3, 3), torch.zeros(1, 2, 518, 518, 1),
+            torch.zeros(1, 2, 518, 518), [], [])
