@@ -37,7 +37,7 @@ extern "C" {
  * 3: + head-parallel sharding (ovg_attn_params.kv_heads / out_bh_stride, ovg_block_params.skip_attention, ovg_heads_to_tokens)
  * 4: per-call GEMM tile selector (`tile`) replacing the process-global debug setter of ABI 3, optional
  *    log-sum-exp output of ovg_flash_attn + ovg_attn_merge (two-launch local-first sharded attention),
- *    ovg_block_workspace_bytes, ovg_pack_weights */
+ *    ovg_block_workspace_bytes, ovg_pack_weights, split-KV attention (kv_splits / ws_part / ws_lse, ovg_attn_plan) */
 #define OVG_ABI_VERSION 4
 
 enum { OVG_BF16 = 0, OVG_F16 = 1, OVG_F32 = 2 };
@@ -163,8 +163,20 @@ typedef struct {
    * pre-scaled logits). With it, two calls over disjoint key sets are combined exactly by ovg_attn_merge --
    * the view-sharded all-gather path runs the local keys while the remote ones are still in flight. */
   float* lse;
+  /* Split-KV (16-bit dtypes): a launch whose (batch entry, q tile) units do not fill the chip evenly -- 688 workgroups
+   * on 512 resident slots at 8 views, the same per rank of an 8-GPU run -- is cut along the KEY axis into kv_splits
+   * passes per unit; every pass writes a normalised partial result + its log-sum-exp into the caller's workspace and
+   * a second (tiny) launch combines them exactly. kv_splits: 0 = the library decides (ovg_attn_plan; never splits
+   * when ws_part / ws_lse are NULL), 1 = never, 2..8 = force. ws_part: `part_bytes`, ws_lse: `lse_bytes` of ovg_attn_plan.
+   * Units of one (batch entry, split) run next to each other, so the K / V^T range an XCD streams shrinks by kv_splits. */
+  int kv_splits; void* ws_part; float* ws_lse;
 } ovg_attn_params;
 int ovg_flash_attn(const ovg_attn_params*, void* stream);
+
+/* Host-only query: how ovg_flash_attn would run this call with kv_splits == 0 (needs nq, BH, dtype, variant, the
+ * segments' nk; pointers are ignored) and how much split workspace the caller should provide for it. */
+typedef struct { int splits; int q_tile; int64_t part_bytes; int64_t lse_bytes; } ovg_attn_plan_out;
+int ovg_attn_plan(const ovg_attn_params*, ovg_attn_plan_out* out);
 
 /* Combine two attention results over disjoint key sets (same queries):
  *   w_a = 2^(lse_a - m), w_b = 2^(lse_b - m), m = max(lse_a, lse_b);  out = (w_a * a + w_b * b) / (w_a + w_b)
@@ -225,6 +237,8 @@ typedef struct {
   void* ev_attn_start; void* ev_attn_stop;
   int skip_attention;  /* ovg_block_attn_epilogue only: ws_attn already holds the attention output (head-parallel sharding) */
   int gemm_tile;       /* OVG_TILE_* forwarded to the four GEMMs of the block (tests force a tile; 0 in production) */
+  /* optional split-KV workspace of the block's attention launch (ovg_attn_params.ws_part / ws_lse; NULL = never split) */
+  void* ws_attn_part; float* ws_attn_lse; int attn_kv_splits;
 } ovg_block_params;
 /* whole block */
 int ovg_block_forward(const ovg_block_params*, void* stream);

@@ -104,6 +104,16 @@ class Workspace:
             self.hid = torch.empty(M, 4 * C, device=device, dtype=dtype)
         rows = seq if kv_rows is None else kv_rows
         self.q, self.k, self.vt = ops.alloc_qkv(self.BH, rows, rows, dtype, device)
+        self.device, self._split = device, {}
+
+    def split_ws(self, variant=0):
+        """(ws_part, ws_lse) for this shape's self-attention launch if ovg_attn_plan wants to split it along the keys
+        (launches that would leave CUs idle: 8-view global attention = 688 workgroups on 512 slots), else (None, None)."""
+        if variant not in self._split:
+            plan = (ops.attn_plan(self.BH, self.seq, [self.seq], self.dtype, variant, nq_pad=self.q.shape[1])
+                    if self.dtype != torch.float32 else {"splits": 1})
+            self._split[variant] = ops.alloc_split_ws(plan, self.device)
+        return self._split[variant]
 
     def share_from(self, other):
         """Reuse the LN / attention / hidden scratch of another workspace with the same M."""
@@ -164,6 +174,10 @@ class BlockRunner:
                                                                   L.ptr(ws.attn), L.ptr(ws.hid))
         p.attn_variant = int(getattr(self.knobs, "attn_variant", 0))
         p.gemm_tile = int(getattr(self.knobs, "gemm_tile", 0))
+        p.attn_kv_splits = int(getattr(self.knobs, "attn_kv_splits", 0))
+        if p.attn_kv_splits != 1 and hasattr(ws, "split_ws"):
+            part, lse = ws.split_ws(p.attn_variant)
+            p.ws_attn_part, p.ws_attn_lse = L.ptr(part), L.ptr(lse)
         return p
 
     def forward(self, ws, x_in, x_out, inject=None, inj_period=0, events=None, **kw):
@@ -223,6 +237,7 @@ class ZeroAggregator(nn.Module):
         self.compute_dtype = compute_dtype
         self.attn_variant = 0       # ovg_attn_params.variant of every attention call (0 = library default); read per call
         self.gemm_tile = 0          # OVG_TILE_* forced on the block GEMMs (tests); 0 = shape heuristic
+        self.attn_kv_splits = 0     # ovg_attn_params.kv_splits: 0 = library decides per launch, 1 = never split
         self.max_workspaces = 4     # scratch shapes kept alive (frame + global of the two most recent geometries)
         self.shard = None           # set by sharding.ViewSharding for the multi-GPU path
         self._packed = None

@@ -267,44 +267,99 @@ int launch_attn(const ovg_attn_params& p, hipStream_t st) {
   return OVG_OK;
 }
 
-template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false>
-int launch_attn16(const ovg_attn_params& p, hipStream_t st) {
-  constexpr int BQ = 16 * QB * WAVES;
-  const int nqt = (int)((p.nq + BQ - 1) / BQ);
+// ---- launch plan of the 16-bit kernels: q tile (256 or 512 rows) and split-KV factor ---------------------------------
+// `slots` = workgroups resident at once (256 CUs x 2 workgroups of 4 waves, or x 1 of 8 waves). A launch of U equal units
+// takes ceil(U / slots) rounds; cutting every unit into s key ranges makes the rounds 1/s as long at ~1.5 key tiles of
+// fixed cost per unit (anchor prologue, Q load, epilogue). The default q tile is 256 rows; launches of >= 8 full rounds of
+// 512-row tiles take those (1 workgroup of 8 waves per CU: every staged K / V^T tile feeds twice the rows; +2.2 % at
+// 64 views, -17 % at 8 views -- profiles/r02_attention_variants_ab.txt).
+struct Plan16 { int variant; int bq; int splits; int per_split; int total_tiles; };
+
+int cu_count_attn() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    return v;
+  }();
+  return n;
+}
+
+int total_key_tiles(const ovg_attn_params& p) {
   int total = 0;
   for (int i = 0; i < p.nseg; ++i) total += (int)((p.seg[i].nk + BC - 1) / BC);
-  const dim3 grid((unsigned)(p.BH * nqt)), block(64 * WAVES);
-  OVG_LAUNCH((attn16_kernel<T, QB, WAVES, MODE, OCC, VSUM>), grid, block, 0, st, p, nqt, total);
+  return total;
+}
+
+Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
+  Plan16 pl{};
+  int v = p.variant;
+  const int cus = cu_count_attn();
+  const int64_t units512 = p.BH * ((p.nq + 511) / 512);
+  if (v == 0) v = bf16 ? (units512 >= 8 * (int64_t)cus ? 33 : 21) : (p.nq >= 4096 ? 6 : 8);
+  pl.variant = v;
+  pl.bq = (v == 33) ? 512 : ((v == 8 || v == 25 || v == 19) ? 128 : ((v == 32) ? 256 : 256));
+  pl.total_tiles = total_key_tiles(p);
+  const int slots = (v == 33) ? cus : 2 * cus;
+  const int64_t units = p.BH * ((p.nq + pl.bq - 1) / pl.bq);
+  int splits = 1;
+  if (p.kv_splits > 1) splits = p.kv_splits;
+  else if (p.kv_splits == 0 && have_ws && (v == 21 || v == 6 || v == 33)) {
+    double best = (double)((units + slots - 1) / slots) * (1.0 + 1.5 / pl.total_tiles);
+    for (int s = 2; s <= OVG_MAX_SEG; ++s) {
+      const int per = (pl.total_tiles + s - 1) / s;
+      if (per < 16) break;
+      const double cost = (double)((units * s + slots - 1) / slots) / s * (1.0 + 1.5 / per);
+      if (cost < best * 0.97) { best = cost; splits = s; }
+    }
+  }
+  if (splits > OVG_MAX_SEG) splits = OVG_MAX_SEG;
+  if (splits > pl.total_tiles) splits = pl.total_tiles;
+  pl.per_split = (pl.total_tiles + splits - 1) / splits;
+  pl.splits = (pl.total_tiles + pl.per_split - 1) / pl.per_split;       // every pass non-empty
+  return pl;
+}
+
+template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false>
+int launch_attn16(const ovg_attn_params& p, const Plan16& pl, hipStream_t st) {
+  constexpr int BQ = 16 * QB * WAVES;
+  const int nqt = (int)((p.nq + BQ - 1) / BQ);
+  const dim3 grid((unsigned)(p.BH * nqt * pl.splits)), block(64 * WAVES);
+  OVG_LAUNCH((attn16_kernel<T, QB, WAVES, MODE, OCC, VSUM>), grid, block, 0, st, p, nqt, pl.total_tiles, pl.splits, pl.per_split);
   OVG_CHECK_LAUNCH();
+  if (pl.splits > 1) {
+    const int64_t total = p.BH * p.nq * 8;
+    const int64_t blocks = (total + 255) / 256;
+    OVG_LAUNCH((attn_split_merge_kernel<T>), dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, p, pl.splits, total);
+    OVG_CHECK_LAUNCH();
+  }
   return OVG_OK;
 }
 
 // variant (benchmark / test knob; numbers kept from the A/B logs under profiles/):
-//   0 = default: bf16 -> speculative kernel (QB = 4), f16 -> lazy-rescale kernel (QB = 4 for nq >= 4096, else 2)
-//   1 / 2   baseline kernel, QB = 1 / 2
+//   0 = default: bf16 -> speculative kernel, q tile and split-KV factor from plan16; f16 -> lazy-rescale kernel
+//   1 / 2   baseline kernel, QB = 1 / 2 (never split)
 //   6 / 8   attn16 lazy-rescale only (MODE 1), QB = 4 / 2
 //   21 / 25 attn16 speculative + verified fallback (MODE 0), QB = 4 / 2
 //   18 / 19 attn16 with the fallback forced (MODE 2, tests), QB = 4 / 2
+//   31 / 32 r02 experiments: row sums on the VALU / 8 waves x 32 rows at 4 waves per SIMD (both slower, kept for the A/B tool)
+//   33      8 waves x 64 rows = 512-row q tiles, 1 workgroup per CU (chosen automatically for launches of >= 8 rounds)
 template <typename T>
 int dispatch16(const ovg_attn_params& p, hipStream_t st) {
   constexpr bool kBf16 = std::is_same<T, bf16_t>::value;
-  int v = p.variant;
-  // measured (profiles/r01_attention_attn16_ab.txt): the speculative kernel is best at QB = 4 for both the global
-  // (nq = S * 1374) and the frame (nq = 1374) shapes; the lazy kernel prefers QB = 2 on the short one
-  if (v == 0) v = kBf16 ? 21 : (p.nq >= 4096 ? 6 : 8);
-  switch (v) {
+  const Plan16 pl = plan16(p, kBf16, p.ws_part != nullptr && p.ws_lse != nullptr);
+  if (pl.splits > 1 && (p.ws_part == nullptr || p.ws_lse == nullptr)) return OVG_E_ARG;
+  switch (pl.variant) {
     case 1: return launch_attn<T, 1>(p, st);
     case 2: return launch_attn<T, 2>(p, st);
-    case 6: return launch_attn16<T, 4, 4, 1>(p, st);
-    case 8: return launch_attn16<T, 2, 4, 1>(p, st);
-    case 21: return launch_attn16<T, 4, 4, 0>(p, st);
-    case 25: return launch_attn16<T, 2, 4, 0>(p, st);
-    case 18: return launch_attn16<T, 4, 4, 2>(p, st);
-    case 19: return launch_attn16<T, 2, 4, 2>(p, st);
-    // r02 experiments (tests/bench_kernels.py attn; results in profiles/r02_attention_variants_ab.txt)
-    case 31: return launch_attn16<T, 4, 4, 0, 2, true>(p, st);    // row sums on the VALU instead of the ones-MFMA
-    case 32: return launch_attn16<T, 2, 8, 0, 4>(p, st);          // 8 waves x 32 rows, <= 128 VGPRs: 2 workgroups = 4 waves per SIMD
-    case 33: return launch_attn16<T, 4, 8, 0, 2>(p, st);          // 8 waves x 64 rows = 512-row q tiles, 1 workgroup per CU
+    case 6: return launch_attn16<T, 4, 4, 1>(p, pl, st);
+    case 8: return launch_attn16<T, 2, 4, 1>(p, pl, st);
+    case 21: return launch_attn16<T, 4, 4, 0>(p, pl, st);
+    case 25: return launch_attn16<T, 2, 4, 0>(p, pl, st);
+    case 18: return launch_attn16<T, 4, 4, 2>(p, pl, st);
+    case 19: return launch_attn16<T, 2, 4, 2>(p, pl, st);
+    case 31: return launch_attn16<T, 4, 4, 0, 2, true>(p, pl, st);
+    case 32: return launch_attn16<T, 2, 8, 0, 4>(p, pl, st);
+    case 33: return launch_attn16<T, 4, 8, 0, 2>(p, pl, st);
     default: return OVG_E_ARG;
   }
 }
@@ -322,6 +377,9 @@ extern "C" int ovg_flash_attn(const ovg_attn_params* p, void* stream) {
   }
   if ((reinterpret_cast<uintptr_t>(p->q) | reinterpret_cast<uintptr_t>(p->out)) & 15) return OVG_E_ARG;
   if (p->lse && (reinterpret_cast<uintptr_t>(p->lse) & 3)) return OVG_E_ARG;
+  if (p->kv_splits < 0 || p->kv_splits > OVG_MAX_SEG) return OVG_E_ARG;
+  if ((p->ws_part && (reinterpret_cast<uintptr_t>(p->ws_part) & 15)) || (p->ws_lse && (reinterpret_cast<uintptr_t>(p->ws_lse) & 3))) return OVG_E_ARG;
+  if (p->kv_splits > 1 && (p->dtype == OVG_F32 || p->variant == 1 || p->variant == 2)) return OVG_E_UNSUPPORTED;   // the baseline kernel never splits
   if (p->ldo % 4 || p->kv_heads < 0 || p->out_bh_stride < 0 || (p->out_bh_stride > 0 && (p->ldo < OVG_D || p->out_bh_stride % 4))) return OVG_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (p->dtype) {
@@ -330,4 +388,21 @@ extern "C" int ovg_flash_attn(const ovg_attn_params* p, void* stream) {
     case OVG_F32: return launch_attn<float, 1>(*p, st);
     default: return OVG_E_DTYPE;
   }
+}
+
+extern "C" int ovg_attn_plan(const ovg_attn_params* p, ovg_attn_plan_out* out) {
+  if (!p || !out || p->nq <= 0 || p->BH <= 0 || p->nseg < 1 || p->nseg > OVG_MAX_SEG || p->kv_splits < 0 || p->kv_splits > OVG_MAX_SEG) return OVG_E_ARG;
+  for (int i = 0; i < p->nseg; ++i)
+    if (p->seg[i].nk <= 0) return OVG_E_ARG;
+  out->splits = 1; out->q_tile = 64; out->part_bytes = 0; out->lse_bytes = 0;
+  if (p->dtype != OVG_BF16 && p->dtype != OVG_F16) return p->dtype == OVG_F32 ? OVG_OK : OVG_E_DTYPE;
+  const Plan16 pl = plan16(*p, p->dtype == OVG_BF16, true);
+  if (pl.variant == 1 || pl.variant == 2) return OVG_OK;
+  const int64_t nq_pad = p->nq_pad >= p->nq ? p->nq_pad : ((p->nq + BC - 1) / BC) * BC;
+  out->splits = pl.splits; out->q_tile = pl.bq;
+  if (pl.splits > 1) {
+    out->part_bytes = (int64_t)pl.splits * p->BH * nq_pad * OVG_D * 2;
+    out->lse_bytes = (int64_t)pl.splits * p->BH * nq_pad * 4;
+  }
+  return OVG_OK;
 }

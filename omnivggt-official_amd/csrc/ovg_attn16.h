@@ -101,8 +101,8 @@ OVG_DEV u32x4 pack2(const f32x4 a, const f32x4 b) {
 // O^T in o, the row sums in lacc (every register of lacc[qb] holds the full sum of row q0 + 16 qb + lane&15) and the
 // negated reference maximum in negm (P = exp2(s + negm)): log2 sum_k exp2(s) = log2(lacc) - negm.
 template <typename T, int QB, int WAVES, int SM, bool VSUM = false>   // VSUM: row sums on the VALU (experiment, variant 31) instead of the ones-MFMA
-OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int bh, const int q0, const int total_tiles,
-                       f32x4 (&o)[QB][4], f32x4 (&lacc)[QB], f32x4 (&negm)[QB]) {
+OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int bh, const int q0, const int t_begin, const int total_tiles,
+                       f32x4 (&o)[QB][4], f32x4 (&lacc)[QB], f32x4 (&negm)[QB]) {   // key tiles [t_begin, t_begin + total_tiles) of the flattened segment list
   constexpr int NT = 64 * WAVES;
   constexpr int RB = 128, KT_B = BC * RB, VT_B = OVG_D * RB, CPT = 512 / NT;
   const int tid = threadIdx.x;
@@ -144,12 +144,14 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
     v_loff0[i] = swz_off<128>(row, 4 * u + 2 * (c4 & 1) + 0) + 8 * (c4 >> 1);
     v_loff1[i] = swz_off<128>(row, 4 * u + 2 * (c4 & 1) + 1) + 8 * (c4 >> 1);
   }
-  int fseg = 0, ftile = 0;
+  int fseg = 0, ftile = t_begin;                   // split-KV: this pass starts t_begin tiles into the segment list
   int f_ntiles = (int)((p.seg[0].nk + BC - 1) / BC);
+  while (ftile >= f_ntiles) { ftile -= f_ntiles; ++fseg; f_ntiles = (int)((p.seg[fseg].nk + BC - 1) / BC); }
   const int kvh = p.kv_heads > 0 ? bh % p.kv_heads : bh;   // head-parallel sharding: (source rank, head) pairs share K / V^T
-  const unsigned char* kptr = static_cast<const unsigned char*>(p.seg[0].k) + (int64_t)kvh * p.seg[0].nk_pad * RB;
-  const unsigned char* vptr = static_cast<const unsigned char*>(p.seg[0].vt) + (int64_t)kvh * OVG_D * p.seg[0].nk_pad * 2;
-  int64_t vstride = p.seg[0].nk_pad * 2;          // bytes between V^T rows (d)
+  const unsigned char* kptr = static_cast<const unsigned char*>(p.seg[fseg].k) + ((int64_t)kvh * p.seg[fseg].nk_pad + (int64_t)ftile * BC) * RB;
+  const unsigned char* vptr = static_cast<const unsigned char*>(p.seg[fseg].vt) + ((int64_t)kvh * OVG_D * p.seg[fseg].nk_pad + (int64_t)ftile * BC) * 2;
+  int64_t vstride = p.seg[fseg].nk_pad * 2;       // bytes between V^T rows (d)
+  const int seg0 = fseg, tile0 = ftile;
   auto fetch = [&]() {
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
@@ -180,9 +182,9 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
     }
   };
 
-  int cseg = 0, ctile = 0;
+  int cseg = seg0, ctile = tile0;
   int c_ntiles = f_ntiles;
-  int c_nk = (int)p.seg[0].nk;
+  int c_nk = (int)p.seg[seg0].nk;
   const int sx = lr >> 1;
   const int frag_row = lr * 128;
   const int coff0 = ((0 + g) ^ sx) << 4, coff1 = ((4 + g) ^ sx) << 4;
@@ -251,7 +253,7 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
   if constexpr (SM == 2) {
     // anchor: m_ref = row max over the first key tile (tile 0 is in LDS buffer 0 now)
     f32x4 s[4][QB];
-    qk_tile(lds, s, BC > c_nk, 0);
+    qk_tile(lds, s, (tile0 + 1) * BC > c_nk, tile0 * BC);
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       const float mx = row_max(s, qb) + AnchorMargin<T>::value;
@@ -317,23 +319,28 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
 
 // MODE: 0 = speculative anchored softmax + verified fallback, 1 = lazy-rescale only, 2 = forced fallback (tests)
 template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false>   // OCC: minimum waves per SIMD the register allocation must allow
-__global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params p, int nqt, int total_tiles) {
+__global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params p, int nqt, int total_tiles, int splits, int per_split) {
   static_assert(sizeof(T) == 2, "16-bit types only");
   constexpr int RB = 128, KT_B = BC * RB, VT_B = OVG_D * RB, BQ = 16 * QB * WAVES;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (KT_B + VT_B)];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, lr = lane & 15;
+  // logical id -> (batch entry, key split, q tile), q tile fastest: the workgroups that run side by side on an XCD share
+  // one (entry, split) = one K / V^T range, which with splits is 1 / splits of the head's keys
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = lid / nqt, qt = lid % nqt;
+  const int qt = lid % nqt, rest = lid / nqt;
+  const int sp = rest % splits, bh = rest / splits;
   const int nq = (int)p.nq;
   const int q0 = qt * BQ + wave * 16 * QB;
+  const int t0 = sp * per_split;
+  const int nt = (total_tiles - t0) < per_split ? (total_tiles - t0) : per_split;   // >= 1: the host sizes splits so that every pass has keys
 
   f32x4 o[QB][4], lacc[QB], negm[QB];
   if constexpr (MODE == 1) {
-    attn16::run_tiles<T, QB, WAVES, 0, VSUM>(p, lds, bh, q0, total_tiles, o, lacc, negm);
+    attn16::run_tiles<T, QB, WAVES, 0, VSUM>(p, lds, bh, q0, t0, nt, o, lacc, negm);
   } else {
-    attn16::run_tiles<T, QB, WAVES, 2, VSUM>(p, lds, bh, q0, total_tiles, o, lacc, negm);
+    attn16::run_tiles<T, QB, WAVES, 2, VSUM>(p, lds, bh, q0, t0, nt, o, lacc, negm);
     bool bad = MODE == 2;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params
 #pragma unroll
         for (int r = 0; r < 4; ++r) bad = bad || attn16::nonfinite(o[qb][dt][r]);
     }
-    if (__syncthreads_or(bad ? 1 : 0)) attn16::run_tiles<T, QB, WAVES, 0, VSUM>(p, lds, bh, q0, total_tiles, o, lacc, negm);
+    if (__syncthreads_or(bad ? 1 : 0)) attn16::run_tiles<T, QB, WAVES, 0, VSUM>(p, lds, bh, q0, t0, nt, o, lacc, negm);
   }
 
   const int bq = bh / OVG_H, hh = bh % OVG_H;
@@ -352,6 +359,15 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params
     const float inv = 1.0f / lacc[qb][0];        // every row of the ones-MFMA holds the full row sum
     const int q = q0 + qb * 16 + lr;
     if (q < nq) {
+      if (splits > 1) {                           // partial pass: head-major [split][entry][nq_pad][64] + its log-sum-exp
+        const int64_t row = ((int64_t)sp * p.BH + bh) * p.nq_pad + q;
+        T* dst = static_cast<T*>(p.ws_part) + row * OVG_D + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          store4<T>(dst + 16 * dt, o[qb][dt][0] * inv, o[qb][dt][1] * inv, o[qb][dt][2] * inv, o[qb][dt][3] * inv);
+        if (g == 0) p.ws_lse[row] = __builtin_amdgcn_logf(lacc[qb][0]) - negm[qb][0];
+        continue;
+      }
       T* dst = p.out_bh_stride > 0 ? static_cast<T*>(p.out) + (int64_t)bh * p.out_bh_stride + (int64_t)q * p.ldo + 4 * g
                                    : static_cast<T*>(p.out) + ((int64_t)bq * nq + q) * p.ldo + hh * OVG_D + 4 * g;
 #pragma unroll
@@ -359,5 +375,41 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params
         store4<T>(dst + 16 * dt, o[qb][dt][0] * inv, o[qb][dt][1] * inv, o[qb][dt][2] * inv, o[qb][dt][3] * inv);
       if (p.lse != nullptr && g == 0) p.lse[(int64_t)bh * p.nq_pad + q] = __builtin_amdgcn_logf(lacc[qb][0]) - negm[qb][0];
     }
+  }
+}
+
+// Second launch of a split-KV call: out[entry, q, :] = sum_s w_s part[s][entry, q, :] / sum_s w_s, w_s = 2^(lse_s - max lse)
+// (exact: softmax over disjoint key sets combines through the log-sum-exps). One thread = 8 features (16 bytes) of one
+// (entry, query); writes the caller's final layout (token-major or head-major) and, if asked, the total log-sum-exp.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_split_merge_kernel(ovg_attn_params p, int splits, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c = (int)(idx & 7);
+    const int64_t rq = idx >> 3;                       // entry * nq + q
+    const int bh = (int)(rq / p.nq), q = (int)(rq - (int64_t)bh * p.nq);
+    const int64_t row = (int64_t)bh * p.nq_pad + q, stride = p.BH * p.nq_pad;
+    float l[OVG_MAX_SEG], m = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < OVG_MAX_SEG; ++s)
+      if (s < splits) { l[s] = p.ws_lse[s * stride + row]; m = fmaxf(m, l[s]); }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, wsum = 0.f;
+#pragma unroll
+    for (int s = 0; s < OVG_MAX_SEG; ++s)
+      if (s < splits) {
+        const float w = __builtin_amdgcn_exp2f(l[s] - m);
+        wsum += w;
+        const u32x4 raw = *reinterpret_cast<const u32x4*>(static_cast<const T*>(p.ws_part) + (s * stride + row) * OVG_D + c * 8);
+        T v[8];
+        __builtin_memcpy(v, &raw, 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += w * TT<T>::to_f32(v[i]);
+      }
+    const float inv = 1.0f / wsum;
+    const int bq = bh / OVG_H, hh = bh % OVG_H;
+    T* dst = p.out_bh_stride > 0 ? static_cast<T*>(p.out) + (int64_t)bh * p.out_bh_stride + (int64_t)q * p.ldo + c * 8
+                                 : static_cast<T*>(p.out) + ((int64_t)bq * p.nq + q) * p.ldo + hh * OVG_D + c * 8;
+    store4<T>(dst, acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+    store4<T>(dst + 4, acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv);
+    if (p.lse != nullptr && c == 0) p.lse[row] = m + __builtin_amdgcn_logf(wsum);
   }
 }

@@ -49,7 +49,11 @@ class KvSegment(C.Structure):
 class AttnParams(C.Structure):
     _fields_ = [("q", vp), ("nq", i64), ("nq_pad", i64), ("seg", KvSegment * OVG_MAX_SEG), ("nseg", i32),
                 ("out", vp), ("ldo", i64), ("BH", i64), ("dtype", i32), ("variant", i32),
-                ("kv_heads", i32), ("out_bh_stride", i64), ("lse", vp)]
+                ("kv_heads", i32), ("out_bh_stride", i64), ("lse", vp), ("kv_splits", i32), ("ws_part", vp), ("ws_lse", vp)]
+
+
+class AttnPlanOut(C.Structure):
+    _fields_ = [("splits", i32), ("q_tile", i32), ("part_bytes", i64), ("lse_bytes", i64)]
 
 
 class AttnMergeParams(C.Structure):
@@ -74,7 +78,7 @@ class BlockParams(C.Structure):
                 ("ws_xn", vp), ("ws_q", vp), ("ws_k", vp), ("ws_vt", vp), ("ws_attn", vp), ("ws_hid", vp),
                 ("extra", KvSegment * OVG_MAX_SEG), ("nseg_extra", i32), ("local_seg_index", i32),
                 ("attn_variant", i32), ("qkv_part", i32), ("ev_attn_start", vp), ("ev_attn_stop", vp),
-                ("skip_attention", i32), ("gemm_tile", i32)]
+                ("skip_attention", i32), ("gemm_tile", i32), ("ws_attn_part", vp), ("ws_attn_lse", vp), ("attn_kv_splits", i32)]
 
 
 class BlockWorkspace(C.Structure):
@@ -165,6 +169,7 @@ SYMBOLS = {
     "ovg_heads_to_tokens": (i32, [C.POINTER(HeadsToTokensParams), vp]),
     "ovg_probe_mfma": (i32, [vp, vp, vp, i32, vp]),
     "ovg_attn_merge": (i32, [C.POINTER(AttnMergeParams), vp]),
+    "ovg_attn_plan": (i32, [C.POINTER(AttnParams), C.POINTER(AttnPlanOut)]),
     "ovg_block_workspace_bytes": (i32, [C.POINTER(BlockParams), C.POINTER(BlockWorkspace)]),
     "ovg_pack_weights": (i32, [C.POINTER(PackWeightsParams), vp]),
 }

@@ -87,12 +87,35 @@ def qkv(x, w, bias, seq, dtype, q, k, vt, qk_norm=None, rope=None, tokens_per_vi
     L.call("ovg_qkv", p, _stream())
 
 
-def flash_attn(q, segments, nq, dtype, out=None, variant=0, kv_heads=0, head_major=False, lse=None):
+def attn_plan(BH, nq, nks, dtype, variant=0, kv_splits=0, nq_pad=None):
+    """How ovg_flash_attn would run this shape (host-only query): dict(splits, q_tile, part_bytes, lse_bytes).
+    nq_pad: row count of the q buffer the call will use (default: nq padded to 64); the partial buffers are sized with it."""
+    p = L.AttnParams()
+    p.nq, p.nq_pad, p.BH, p.nseg = nq, (pad_to(nq, KV_TILE) if nq_pad is None else nq_pad), BH, len(nks)
+    for i, nk in enumerate(nks):
+        p.seg[i].nk = nk
+    p.dtype, p.variant, p.kv_splits = L.dtype_code(dtype), variant, kv_splits
+    out = L.AttnPlanOut()
+    L.check(L.load().ovg_attn_plan(L.C.byref(p), L.C.byref(out)), "ovg_attn_plan")
+    return {"splits": out.splits, "q_tile": out.q_tile, "part_bytes": out.part_bytes, "lse_bytes": out.lse_bytes}
+
+
+def alloc_split_ws(plan, device):
+    """(ws_part, ws_lse) byte/f32 buffers for a plan with splits > 1, else (None, None)."""
+    if plan["splits"] <= 1:
+        return None, None
+    return (torch.empty(plan["part_bytes"], device=device, dtype=torch.uint8),
+            torch.empty(plan["lse_bytes"] // 4, device=device, dtype=torch.float32))
+
+
+def flash_attn(q, segments, nq, dtype, out=None, variant=0, kv_heads=0, head_major=False, lse=None, kv_splits=0, split_ws=None):
     """q [BH,nq_pad,64]; segments: list of (k [BHkv,nk_pad,64], vt [BHkv,64,nk_pad], nk).
     Returns out [B*nq, 1024] token-major, or with head_major=True out [BH, nq_pad, 64].
     kv_heads > 0: the segments hold kv_heads heads and batch entry bh attends to head bh % kv_heads
     (head-parallel sharding: the BH entries are (source rank, head) pairs).
-    lse: optional f32 [BH, nq_pad] receiving log2(sum_k exp2(logit)) over the keys of this call (see attn_merge)."""
+    lse: optional f32 [BH, nq_pad] receiving log2(sum_k exp2(logit)) over the keys of this call (see attn_merge).
+    kv_splits / split_ws = (ws_part, ws_lse) from alloc_split_ws(attn_plan(...)): split-KV for launches that do not fill the
+    chip evenly (kv_splits 0 = library decides, and only splits when split_ws is given; 1 = never; 2..8 = force)."""
     _chk_dev(q)
     BH = q.shape[0]
     if out is None:
@@ -113,6 +136,10 @@ def flash_attn(q, segments, nq, dtype, out=None, variant=0, kv_heads=0, head_maj
         if lse.dtype != torch.float32 or tuple(lse.shape) != (BH, q.shape[1]) or not lse.is_contiguous():
             raise L.OvgError("lse must be a contiguous f32 [BH, nq_pad] tensor")
         p.lse = L.ptr(lse)
+    p.kv_splits = kv_splits
+    if split_ws is not None and split_ws[0] is not None:
+        _chk_dev(*split_ws)
+        p.ws_part, p.ws_lse = L.ptr(split_ws[0]), L.ptr(split_ws[1])
     L.call("ovg_flash_attn", p, _stream())
     return out
 

@@ -22,10 +22,15 @@ Two exchange forms, both overlapped with compute (ViewSharding(mode=...)):
     send chunk is contiguous and the received K / V^T chunks are used in place as `world` kernel
     segments), attention runs over (source rank, head) batch entries (`kv_heads`), one all-to-all
     returns the head-major outputs, ovg_heads_to_tokens restores the token-major layout.
-    Pipelined in HEAD GROUPS (2 groups when a rank owns >= 2 heads): all inbound exchanges are
-    issued up front on RCCL's stream; the compute stream waits for group 0 only, runs attention(0)
-    while group 1 is still arriving, returns O(0) under attention(1), ... -- about half of the
-    exchange time is hidden, the exposed part is one group's inbound + the last group's return.
+    Pipelined in HEAD GROUPS where that pays (head_groups(): 2 groups while each group's attention
+    launch still covers >= 2 rounds of the chip's 512 workgroup slots -- 2 or 4 ranks at 64 views;
+    at 8 ranks x 8 views a rank owns 2 heads, a per-head launch would be 344 workgroups and the
+    quantisation loss would exceed the exchange it hides, so it stays one launch): all inbound
+    exchanges are issued up front on RCCL's stream; the compute stream waits for group 0 only, runs
+    attention(0) while group 1 is still arriving, returns O(0) under attention(1), ... -- about half
+    of the exchange time is hidden, the exposed part is one group's inbound + the last group's return.
+    Every per-rank attention launch is also cut along the keys where the library's plan says so
+    (split-KV, ovg_attn_plan): 688 workgroups on 512 slots become 3440 fifths.
 
 The mode is a pure function of (S, world, dtype, requested mode), identical on every rank, so the
 ranks agree without talking; an impossible request raises BEFORE any collective is issued.
@@ -66,11 +71,17 @@ def resolve_mode(requested, n_views, world, is_f32):
     return "heads" if (eligible and world > 1) else "allgather"
 
 
-def head_groups(heads_per_rank):
-    """Pipeline groups of the heads form: [(first head, count)] inside a rank's head range."""
+def head_groups(heads_per_rank, world=1, n_tokens=None):
+    """Pipeline groups of the heads form: [(first head, count)] inside a rank's head range. Two groups (exchange of
+    group 1 under attention of group 0) only while EACH group's attention launch still fills the chip: its
+    world * heads * ceil(n / 256) workgroups must cover >= 2 rounds of the 512 resident slots -- at 8 ranks x 8 views a
+    rank owns 2 heads and one launch per head would be 344 workgroups (0.67 of a round): the quantisation loss would
+    dwarf the ~0.15 ms of exchange it hides, so that case stays one group (split-KV keeps its single launch even)."""
     if heads_per_rank < 2:
         return [(0, heads_per_rank)]
     half = heads_per_rank // 2
+    if n_tokens is not None and world * half * ((n_tokens + 255) // 256) < 1024:
+        return [(0, heads_per_rank)]
     return [(0, half), (half, heads_per_rank - half)]
 
 
@@ -98,7 +109,7 @@ class HipExecutor:
     def _cached(self, key, make):
         key = key + (self.agg.compute_dtype,)
         if key not in self._cache:
-            if len(self._cache) >= 4:
+            if len(self._cache) >= 12:
                 self._cache.pop(next(iter(self._cache)))
             self._cache[key] = make()
         return self._cache[key]
@@ -144,11 +155,18 @@ class HipExecutor:
     def _attention(self, q, segs, n, out, lse=None, kv_heads=0, head_major=False):
         """One flash-attention launch, timed with a HIP event pair when bench.py asked for it."""
         nk = sum(s[2] for s in segs)
+        dt, variant = self.agg.compute_dtype, self.agg.attn_variant
+        splits = getattr(self.agg, "attn_kv_splits", 0)
+        split_ws = None
+        if splits != 1 and dt != torch.float32:     # per-rank launches are the ones that quantise badly (688 workgroups on 512 slots)
+            key = ("split", q.shape[0], n, q.shape[1], tuple(s[2] for s in segs), variant, splits)
+            split_ws = self._cached(key, lambda: ops.alloc_split_ws(
+                ops.attn_plan(q.shape[0], n, [s[2] for s in segs], dt, variant, splits, nq_pad=q.shape[1]), self.device))
         ev = self.agg.next_attention_events(4.0 * q.shape[0] * n * nk * 64)
         if ev is not None:
             ev[0].record()
-        ops.flash_attn(q, segs, n, self.agg.compute_dtype, out=out, variant=self.agg.attn_variant, kv_heads=kv_heads,
-                       head_major=head_major, lse=lse)
+        ops.flash_attn(q, segs, n, dt, out=out, variant=variant, kv_heads=kv_heads, head_major=head_major, lse=lse,
+                       kv_splits=splits, split_ws=split_ws)
         if ev is not None:
             ev[1].record()
         return out
@@ -183,7 +201,7 @@ class HipExecutor:
             pad = ws_g.q.shape[1]
             dt, dev = ws_g.q.dtype, self.device
             groups = []
-            for h0, gs in head_groups(16 // world):
+            for h0, gs in head_groups(16 // world, world, n_local * P):
                 groups.append({"h0": h0, "gs": gs,
                                "q": torch.zeros(world, gs, pad, 64, device=dev, dtype=dt), "k": torch.zeros(world, gs, pad, 64, device=dev, dtype=dt),
                                "vt": torch.zeros(world, gs, 64, pad, device=dev, dtype=dt), "o": torch.zeros(world, gs, pad, 64, device=dev, dtype=dt)})

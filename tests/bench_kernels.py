@@ -48,23 +48,26 @@ def attn(args):
             flop = 4.0 * BH * n * n * 64
             ref = ops.flash_attn(q, [(k, vt, n)], n, dt, variant=1).float()
             outs = {}
-            for v in args.variants:
+            combos = [(v, s) for v in args.variants for s in args.kv_splits]      # kv_splits: 1 = never, 0 = the library's plan, 2..8 forced
+            for v, sp in combos:
                 o = torch.empty((BH // 16) * n, 1024, device=DEV, dtype=dt)
-                ops.flash_attn(q, [(k, vt, n)], n, dt, out=o, variant=v)
+                plan = ops.attn_plan(BH, n, [n], dt, v, sp, nq_pad=q.shape[1])
+                ws = ops.alloc_split_ws(plan, DEV) if sp != 1 else None
+                ops.flash_attn(q, [(k, vt, n)], n, dt, out=o, variant=v, kv_splits=sp, split_ws=ws)
                 err = float((o.float() - ref).abs().max() / ref.abs().max())
-                outs[v] = (o, err)
-            times = {v: [] for v in args.variants}
+                outs[(v, sp)] = (o, err, ws, plan["splits"] if sp != 1 else 1)
+            times = {c: [] for c in combos}
             iters = max(2, int(args.target_ms / max(1e-3, flop / 500e12 * 1e3)))
             for _ in range(args.rounds):
-                for v in args.variants:
-                    o = outs[v][0]
-                    times[v].append(timed(lambda: ops.flash_attn(q, [(k, vt, n)], n, dt, out=o, variant=v), iters))
-            for v in args.variants:
-                ms = statistics.median(times[v])
+                for v, sp in combos:
+                    o, _, ws, _ = outs[(v, sp)]
+                    times[(v, sp)].append(timed(lambda: ops.flash_attn(q, [(k, vt, n)], n, dt, out=o, variant=v, kv_splits=sp, split_ws=ws), iters))
+            for v, sp in combos:
+                ms = statistics.median(times[(v, sp)])
                 tf = flop / ms / 1e9
-                print("attn %-6s S=%-3d N=%-6d variant=%d: median %.3f ms (min %.3f)  %.1f TFLOP/s  %.1f%% of 2.5PF  err_vs_v1=%.2e"
-                      % (mode, S, n, v, ms, min(times[v]), tf, tf / 25.0, outs[v][1]), flush=True)
-                out["attn_%s_S%d_v%d" % (mode, S, v)] = {"ms": ms, "tflops": tf, "err": outs[v][1]}
+                print("attn %-6s S=%-3d N=%-6d variant=%d kv_splits=%d(->%d): median %.3f ms (min %.3f)  %.1f TFLOP/s  %.1f%% of 2.5PF  err_vs_v1=%.2e"
+                      % (mode, S, n, v, sp, outs[(v, sp)][3], ms, min(times[(v, sp)]), tf, tf / 25.0, outs[(v, sp)][1]), flush=True)
+                out["attn_%s_S%d_v%d_s%d" % (mode, S, v, sp)] = {"ms": ms, "tflops": tf, "err": outs[(v, sp)][1]}
     return out
 
 
@@ -129,6 +132,7 @@ def main():
     ap.add_argument("--views", type=int, nargs="+", default=[8, 16])
     ap.add_argument("--variants", type=int, nargs="+", default=[1, 6, 8, 21, 25], help="see dispatch16 in ovg_attn.hip")
     ap.add_argument("--modes", nargs="+", default=["global", "frame"])
+    ap.add_argument("--kv-splits", type=int, nargs="+", default=[1], help="attn: split-KV factors to compare (1 = off, 0 = library plan, 2..8 forced)")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--tiles", type=int, nargs="+", default=[1, 2], help="GEMM: ovg_linear_params.tile values to compare (1 = 128^2, 2 = 256^2 ping-pong, ...)")
     ap.add_argument("--square", type=int, nargs="*", default=[], help="GEMM: also time n^3 STORE problems (e.g. 4096 8192)")

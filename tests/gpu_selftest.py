@@ -645,6 +645,38 @@ def test_attn_lse_merge():
             report("attn_lse_%s_v%d" % (name, variant), la[:, :nq], lse_ref_a, 2e-5 if name == "f32" else 2e-3)
             merged = ops.attn_merge(oa, la, ob, lb, dt, out=oa)          # in place on launch A's output, like sharding.py
             report("attn_merge_%s_v%d" % (name, variant), merged, ref, TOL[name] * (1.5 if name != "f32" else 1))
+    # split-KV: forced 2..8 key splits (+ the library's own plan) == the single-pass result, token-major and head-major,
+    # ragged multi-segment key lists, with the total log-sum-exp output
+    for name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        BH, nq, nks = 16, 700, [1374, 999, 64, 2000]
+        q = (rnd(BH, nq, 64, g=g) * 1.2).to(dt)
+        ks = [rnd(BH, nk, 64, g=g).to(dt) for nk in nks]
+        vs = [rnd(BH, nk, 64, g=g).to(dt) for nk in nks]
+        kall, vall = torch.cat(ks, 1).float(), torch.cat(vs, 1).float()
+        ref = attn_reference(q.float(), kall, vall)
+        ref_tok = ref.permute(1, 0, 2).reshape(nq, 1024)
+        lse_ref = torch.logsumexp((q.float() @ kall.transpose(1, 2)) * math.log(2.0), -1) / math.log(2.0)
+        qd, _, _ = ops.alloc_qkv(BH, nq, 64, dt, DEV)
+        qd[:, :nq] = q.to(DEV)
+        segs = []
+        for kk, vv in zip(ks, vs):
+            nk = kk.shape[1]
+            _, kd, vtd = ops.alloc_qkv(BH, 64, nk, dt, DEV)
+            kd[:, :nk] = kk.to(DEV)
+            vtd[:, :, :nk] = vv.transpose(1, 2).to(DEV)
+            segs.append((kd, vtd, nk))
+        for variant in (0, 6, 18, 33):
+            for splits in (0, 2, 3, 5, 8):
+                plan = ops.attn_plan(BH, nq, nks, dt, variant, splits, nq_pad=qd.shape[1])
+                ws = ops.alloc_split_ws(plan, DEV)
+                lse = torch.full((BH, qd.shape[1]), float("nan"), device=DEV)
+                out = ops.flash_attn(qd, segs, nq, dt, variant=variant, kv_splits=splits, split_ws=ws, lse=lse)
+                tag = "attn_splitkv_%s_v%d_s%d(plan %d)" % (name, variant, splits, plan["splits"])
+                report(tag, out, ref_tok, TOL[name] * 1.5)
+                report(tag + ".lse", lse[:, :nq], lse_ref, 2e-3)
+            hm = ops.flash_attn(qd, segs, nq, dt, variant=variant, kv_splits=4, head_major=True,
+                                split_ws=ops.alloc_split_ws(ops.attn_plan(BH, nq, nks, dt, variant, 4, nq_pad=qd.shape[1]), DEV))
+            report("attn_splitkv_%s_v%d_headmajor" % (name, variant), hm[:, :nq], ref, TOL[name] * 1.5)
     # weight pre-pack == torch's own rounding, zero padding
     w = rnd(1024, 3, 14, 14, g=g)
     for name, dt in DT.items():

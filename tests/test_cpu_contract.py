@@ -124,6 +124,8 @@ def test_shard_mode_is_decided_without_communication():
         with pytest.raises(ValueError):
             resolve_mode("heads", *bad)
     assert head_groups(2) == [(0, 1), (1, 1)] and head_groups(1) == [(0, 1)] and head_groups(8) == [(0, 4), (4, 4)]
+    assert head_groups(2, 8, 8 * 1374) == [(0, 2)]                    # 8 ranks x 8 views: 344 workgroups per head -> one group
+    assert head_groups(8, 2, 32 * 1374) == [(0, 4), (4, 4)]           # 2 ranks x 32 views: 1376 workgroups per group -> pipelined
 
 
 def test_hot_path_fails_loudly_on_cpu():

@@ -121,7 +121,7 @@ class OracleExecutor:
         pad = ws.q.shape[1]
         nan = lambda *s: torch.full(s, float("nan"))
         groups = [{"h0": h0, "gs": gs, "q": nan(world, gs, pad, 64), "k": nan(world, gs, pad, 64), "vt": nan(world, gs, 64, pad),
-                   "o": nan(world, gs, pad, 64)} for h0, gs in sharding.head_groups(16 // world)]
+                   "o": nan(world, gs, pad, 64)} for h0, gs in sharding.head_groups(16 // world, world, n_local * P)]
         return ws, ws, {"groups": groups, "o_back": nan(16, pad, 64)}
 
     def global_qkv(self, i, ws, x_in, x_out):
