@@ -18,6 +18,7 @@
 // K/V^T may come as several segments (one per rank of the view-sharded all-gather).
 #include "ovg_common.h"
 #include <type_traits>
+#include <cmath>
 
 namespace {
 
@@ -304,12 +305,24 @@ Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
   int splits = 1;
   if (p.kv_splits > 1) splits = p.kv_splits;
   else if (p.kv_splits == 0 && have_ws && (v == 21 || v == 6 || v == 33)) {
-    double best = (double)((units + slots - 1) / slots) * (1.0 + 1.5 / pl.total_tiles);
+    // Measured model (profiles/r02_attention_splitkv_ab.txt): a launch of R = units / slots rounds runs at eff(R) = 1 - 0.155 / R^1.2
+    // of the many-round rate (0.89 at R = 1.34, 0.95 at 2.7, 0.98 at 5.4: the tail rounds run with fewer co-resident
+    // workgroups and are faster than a full one, so the loss is smaller than ceil(R) / R); a split costs ~1.5 key tiles per
+    // unit plus the partial results' round trip through HBM (in situ ~2.5 TB/s for the write + read-back). Split only for a
+    // >= 3 % estimated gain: single-GPU launches never qualify (8 views: the 90 MB of partials cost what the split gains),
+    // the per-rank launches of the view-sharded run (8 views of queries x 64 views of keys) gain ~7 % at 4 splits.
+    double nk_total = 0;
+    for (int i = 0; i < p.nseg; ++i) nk_total += (double)p.seg[i].nk;
+    const double t0 = 4.0 * p.BH * (double)p.nq * nk_total * OVG_D / 1.2e15;            // seconds at the many-round rate
+    auto eff = [](double R) { return R < 1.0 ? 0.845 * R : 1.0 - 0.155 / pow(R, 1.2); };   // below one round: idle CUs, linear
+    const double R = (double)units / slots;
+    double best = t0 / eff(R);
     for (int s = 2; s <= OVG_MAX_SEG; ++s) {
       const int per = (pl.total_tiles + s - 1) / s;
       if (per < 16) break;
-      const double cost = (double)((units * s + slots - 1) / slots) / s * (1.0 + 1.5 / per);
-      if (cost < best * 0.97) { best = cost; splits = s; }
+      const double part_bytes = 2.0 * s * p.BH * (double)p.nq * OVG_D * 2;
+      const double t = t0 / eff(R * s) * (1.0 + 1.5 / per) + part_bytes / 2.5e12;
+      if (t < best * 0.97) { best = t; splits = s; }
     }
   }
   if (splits > OVG_MAX_SEG) splits = OVG_MAX_SEG;

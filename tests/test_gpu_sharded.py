@@ -161,6 +161,9 @@ def test_two_even_shards_head_parallel_emulated_match_monolithic():
     parts = sharding.partition(S, world)
     hpr = 16 // world
     assert sharding.head_groups(hpr) == [(0, 4), (4, 4)]
+    # force the two-group pipeline for this small case (head_groups() itself would keep one launch at 2 x 1374 tokens)
+    orig_groups = sharding.head_groups
+    sharding.head_groups = lambda h, world=1, n_tokens=None: orig_groups(h)
     ranks = []
     with torch.no_grad():
         for r, (lo, hi) in enumerate(parts):
@@ -191,6 +194,7 @@ def test_two_even_shards_head_parallel_emulated_match_monolithic():
                 buf = st["outs"][i].view(-1, 2 * C)
                 st["ex"].global_finish(i, st["ws_g"], buf[:, :C], buf[:, C:], st["xb"]["o_back"], n)
                 st["x"] = buf[:, C:]
+    sharding.head_groups = orig_groups
     for i in range(agg.depth):
         got = torch.cat([st["outs"][i] for st in ranks], dim=1)
         assert got.shape == ref[i].shape
