@@ -559,21 +559,22 @@ int launch_linear256(const ovg_linear_params& p, hipStream_t st) {
     default: return OVG_E_ARG;
   }
 }
-// Tile choice for the 16-bit modes (measured: tests/bench_kernels.py gemm, profiles/r02_gemm_epilogue_mlp.txt): with the
-// r02 epilogues the 256 x 256 ping-pong loop wins on QKV / fc1 / fc2 at every token count of the benches (M = 10 992:
-// +7 / +13 / +19 %, M = 87 936: +28 / +5 / +17 %), also where its grid quantises badly (QKV at M = 10 992: 516 tiles = 2.02
-// rounds) or leaves CUs idle (fc2 at M = 10 992: 172 tiles); the proj GEMM (K = 1024, f32 residual epilogue, N = 1024) is a
-// tie at M = 87 936 and better on 128 x 128 below (3 workgroups per CU hide the residual round trips). Tiny problems
-// (fewer 256 x 256 tiles than half the CUs) stay on 128 x 128.
+// Tile choice for the 16-bit modes. Isolated A/B (tests/bench_kernels.py gemm, profiles/r02_gemm_epilogue_mlp.txt): with the
+// r02 epilogues the 256 x 256 ping-pong loop wins on QKV / fc1 / fc2 at both bench sizes (M = 10 992: +7 / +13 / +19 %,
+// M = 87 936: +28 / +5 / +17 %); the proj GEMM (K = 1024, f32 residual epilogue) is a tie at M = 87 936 and better on
+// 128 x 128 below. IN SITU the picture differs for short token slices: at 8 views the whole forward is 3 % FASTER with
+// 128 x 128 everywhere (44.4 vs 45.7 ms, profiles/r02_gemm_tile_in_situ.txt) -- the global-attention launches that follow
+// the denser 256 x 256 GEMMs run 9 % slower (0.533 vs 0.488 ms: the chip is power-limited, rocprofv3 shows the GEMMs at
+// 1.8-1.9 GHz and attention at 2.1-2.2 GHz, and the GEMMs' own in-situ gain shrinks with cold L2s and one workgroup per
+// CU). So the 256 x 256 kernels are used from M >= 32 768 rows (24 views), where they are worth +2 % on the 64-view forward.
 // Returns 1 = use 256^2, 0 = use 128^2, -1 = the caller forced a tile this shape / dtype cannot run.
 int choose_256(int tile, bool sixteen_bit, int64_t M, int64_t N, int64_t K, bool light_epilogue_or_long_k) {
   const bool legal = sixteen_bit && N % g256::BN2 == 0 && K % 32 == 0;
   if (tile == OVG_TILE_128) return 0;
   if (tile == OVG_TILE_256) return legal ? 1 : -1;
   if (tile != OVG_TILE_AUTO) return -1;
-  if (!legal || !light_epilogue_or_long_k) return 0;
-  const int64_t tiles = ((M + g256::BM2 - 1) / g256::BM2) * (N / g256::BN2);
-  return tiles >= 128 ? 1 : 0;
+  if (!legal || !light_epilogue_or_long_k || M < 32768) return 0;
+  return 1;
 }
 
 template <typename T>
