@@ -307,7 +307,7 @@ class ZeroAggregator(nn.Module):
             return pk["pos_embed"]
         key = ("pos", gh, gw)
         if key not in pk:
-            pe = self.patch_embed.pos_embed.detach().float().cpu()
+            pe = pk["pos_embed"].detach().float().cpu().unsqueeze(0)      # the packed copy: the module parameter may be on meta (from_packed)
             M = self.grid
             patch = torch.nn.functional.interpolate(pe[:, 1:].reshape(1, M, M, C).permute(0, 3, 1, 2), mode="bicubic",
                                                     antialias=True, size=(gh, gw))
@@ -322,13 +322,16 @@ class ZeroAggregator(nn.Module):
             self.compute_dtype = dtype
             self.invalidate()
 
-    def pack(self, device):
-        """One-time pre-pack after load_state_dict: GEMM weights -> compute dtype, the rest f32."""
-        if self._packed is not None and self._packed["device"] == device and self._packed["dtype"] == self.compute_dtype:
+    def pack(self, device, sd=None):
+        """One-time pre-pack after load_state_dict: GEMM weights -> compute dtype, the rest f32.
+        sd: use this state dict instead of the module's parameters -- export_packed() output read back from disk, whose
+        GEMM weights are already in the compute dtype (and the two Conv2d patch weights already 2-D, zero padded)."""
+        if sd is None and self._packed is not None and self._packed["device"] == device and self._packed["dtype"] == self.compute_dtype:
             return self._packed
         L.require_gpu()
         dt = self.compute_dtype
-        sd = {k: v for k, v in self.state_dict().items()}
+        if sd is None:
+            sd = {k: v for k, v in self.state_dict().items()}
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         rope = make_rope_tables(ROPE_MAX_POS, device, self.rope_freq)
         pk = {"device": device, "dtype": dt, "rope": rope}
@@ -337,6 +340,8 @@ class ZeroAggregator(nn.Module):
         pk["global"] = [BlockRunner(sd, "global_blocks.%d" % i, dt, device, True, True, 1e-5, rope, knobs=self) for i in range(self.depth)]
 
         def conv_as_gemm(w, k_pad):          # Conv2d(k=14, s=14) weight [1024, C_in, 14, 14] -> GEMM rows [1024, k_pad]
+            if w.dim() == 2 and w.shape[1] == k_pad and w.dtype == dt:      # already packed (load_packed)
+                return w.detach().to(device).contiguous()
             return ops.pack_weights(w.detach().to(device), dt, k_pad=k_pad)
 
         pk["patch_w"] = conv_as_gemm(sd["patch_embed.patch_embed.proj.weight"], 640)
@@ -360,6 +365,35 @@ class ZeroAggregator(nn.Module):
         pk["adapt_w"] = [f32(sd["camera_adapters.%d.weight" % i]) for i in range(G)]
         pk["adapt_b"] = [f32(sd["camera_adapters.%d.bias" % i]) for i in range(G)]
         self._packed = pk
+        return pk
+
+    # ------------------------------------------------------------------
+    # persisted pre-packed weights: the reference converts nothing, it keeps f32 masters and starts every
+    # process with a 25 s initialiser + a torch.hub call + a 5 GB f32 checkpoint read (inference.py:321-325). Here the
+    # packed form -- GEMM weights in the compute dtype, conv patch weights as padded GEMM rows, everything else f32 -- can be
+    # written once and mapped back without running pack_weights or holding f32 masters of the 1.2 G GEMM parameters.
+    PACKED_GEMM_KEYS = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")
+
+    def export_packed(self, device):
+        """{state-dict key: tensor} in packed form (device tensors; the caller moves / saves them)."""
+        pk = self.pack(device)
+        out = {k: v.detach() for k, v in self.state_dict().items()}
+        for group, prefix in (("dino", "patch_embed.blocks"), ("frame", "frame_blocks"), ("global", "global_blocks")):
+            for i, runner in enumerate(pk[group]):
+                for name in self.PACKED_GEMM_KEYS:
+                    out["%s.%d.%s" % (prefix, i, name)] = runner.tensors[name]
+        out["patch_embed.patch_embed.proj.weight"] = pk["patch_w"]
+        out["depth_patch_embed.proj.weight"] = pk["depth_w"]
+        return out
+
+    def load_packed(self, sd, device):
+        """Install export_packed() output (any device) as this aggregator's packed weights; the module's own parameters are
+        not touched (they may stay on the meta device: forward() only reads the packed form)."""
+        want = next(v.dtype for k, v in sd.items() if k.endswith("global_blocks.0.attn.qkv.weight"))
+        if want != self.compute_dtype:
+            raise ValueError("packed weights are %s but compute_dtype is %s" % (want, self.compute_dtype))
+        self._packed = None
+        pk = self.pack(device, sd=sd)
         return pk
 
     def workspace(self, M, seq, device):

@@ -67,6 +67,46 @@ class OmniVGGT(nn.Module, _HubMixin):
         model.load_state_dict(load_file(path), strict=True)
         return model.to(device).eval()
 
+    # ---- persisted pre-packed weights ---------------------------------------------------------------
+    def save_packed(self, path, device="cuda"):
+        """Write this model's weights in packed form: aggregator GEMM weights in the current 16-bit compute dtype (half the
+        bytes of the f32 checkpoint), conv patch weights as padded GEMM rows, every other tensor (norms, biases, tokens,
+        heads) f32 -- one safetensors file that from_packed() maps back without any conversion."""
+        from safetensors.torch import save_file
+        dt = self.aggregator.compute_dtype
+        if dt == torch.float32:
+            raise ValueError("packed files are for the 16-bit modes; the f32 mode loads the original checkpoint")
+        tensors = {"aggregator." + k: v.detach().cpu().contiguous() for k, v in self.aggregator.export_packed(torch.device(device)).items()}
+        for k, v in self.state_dict().items():
+            if not k.startswith("aggregator."):
+                tensors[k] = v.detach().cpu().contiguous()
+        save_file(tensors, path, metadata={"format": "omnivggt_official_amd.packed", "version": "1", "compute_dtype": str(dt).replace("torch.", ""),
+                                           "depth": str(self.aggregator.depth), "dino_depth": str(self.aggregator.dino_depth)})
+        return path
+
+    @classmethod
+    def from_packed(cls, path, device="cuda", **kwargs):
+        """Start-up path of a serving process: meta-device construction (no initialiser, no torch.hub), the heads materialised
+        from the file, the aggregator's packed weights installed directly (no f32 masters of the GEMM weights, no
+        pack_weights pass). The aggregator's nn.Parameters stay on the meta device: use the original checkpoint +
+        load_state_dict when a state_dict() of real tensors is needed."""
+        from safetensors import safe_open
+        from safetensors.torch import load_file
+        with safe_open(path, framework="pt") as f:
+            meta = f.metadata() or {}
+        if meta.get("format") != "omnivggt_official_amd.packed":
+            raise ValueError("%s is not a packed OmniVGGT file (use from_safetensors for reference checkpoints)" % path)
+        dt = getattr(torch, meta["compute_dtype"])
+        with torch.device("meta"):
+            model = cls(compute_dtype=dt, depth=int(meta["depth"]), dino_depth=int(meta["dino_depth"]), **kwargs)
+        tensors = load_file(path, device=str(device))
+        for name in ("camera_head", "point_head", "depth_head"):
+            head = getattr(model, name)
+            head.to_empty(device=device)
+            head.load_state_dict({k[len(name) + 1:]: v for k, v in tensors.items() if k.startswith(name + ".")}, strict=True)
+        model.aggregator.load_packed({k[len("aggregator."):]: v for k, v in tensors.items() if k.startswith("aggregator.")}, torch.device(device))
+        return model.eval()
+
     def forward(self, images, extrinsics=None, intrinsics=None, depth=None, mask=None, depth_gt_index=None,
                 camera_gt_index=None):
         if images.dim() == 4:

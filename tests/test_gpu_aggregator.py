@@ -232,6 +232,31 @@ def test_view_permutation_equivariance_at_bench_size():
         assert common.max_rel(b[l].cpu(), a[l][:, perm].cpu()) <= 3e-2
 
 
+def test_packed_weights_roundtrip(tmp_path):
+    """save_packed -> from_packed reproduces the forward bit for bit without f32 masters of the GEMM weights
+    (the aggregator parameters of the reloaded model stay on the meta device), in half the bytes."""
+    sd = common.reduced_state_dict(2, 2)
+    m = build(sd, 2, 2, torch.bfloat16)
+    S, dgi, cgi = 2, [1], [0, 1]
+    ref_toks, _ = run_agg(m, S, dgi, cgi)
+    ref_out = run_full(m, S, dgi, cgi)
+    path = str(tmp_path / "packed.safetensors")
+    m.save_packed(path)
+    full = sum(v.numel() * 4 for v in sd.values())
+    assert os.path.getsize(path) < 0.62 * full
+    m2 = OmniVGGT.from_packed(path)
+    assert m2.aggregator.frame_blocks[0].attn.qkv.weight.is_meta and m2.aggregator.compute_dtype == torch.bfloat16
+    toks, start = run_agg(m2, S, dgi, cgi)
+    out = run_full(m2, S, dgi, cgi)
+    assert start == 5
+    for a, b in zip(toks, ref_toks):
+        assert torch.equal(a, b)
+    for key in ("pose_enc", "depth", "world_points", "depth_conf"):
+        assert torch.equal(out[key], ref_out[key])
+    with pytest.raises(ValueError):
+        OmniVGGT.from_packed(path).aggregator.load_packed({"global_blocks.0.attn.qkv.weight": torch.zeros(1, dtype=torch.float16)}, torch.device(DEV))
+
+
 def test_rejects_bad_inputs():
     sd = common.reduced_state_dict(1, 1)
     m = build(sd, 1, 1, torch.bfloat16)
