@@ -315,44 +315,13 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
   }
 }
 
-}  // namespace attn16
-
-// MODE: 0 = speculative anchored softmax + verified fallback, 1 = lazy-rescale only, 2 = forced fallback (tests)
-template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false>   // OCC: minimum waves per SIMD the register allocation must allow
-__global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params p, int nqt, int total_tiles, int splits, int per_split) {
-  static_assert(sizeof(T) == 2, "16-bit types only");
-  constexpr int RB = 128, KT_B = BC * RB, VT_B = OVG_D * RB, BQ = 16 * QB * WAVES;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (KT_B + VT_B)];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, lr = lane & 15;
-  // logical id -> (batch entry, key split, q tile), q tile fastest: the workgroups that run side by side on an XCD share
-  // one (entry, split) = one K / V^T range, which with splits is 1 / splits of the head's keys
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int qt = lid % nqt, rest = lid / nqt;
-  const int sp = rest % splits, bh = rest / splits;
+// Normalise and store a wave's QB x 16 rows: the caller's final layout (token-major or head-major, + optional log-sum-exp)
+// or, in a split-KV pass, the head-major partial [split][entry][nq_pad][64] with its log-sum-exp.
+template <typename T, int QB>
+OVG_DEV void write_out(const ovg_attn_params& p, const f32x4 (&o)[QB][4], const f32x4 (&lacc)[QB], const f32x4 (&negm)[QB],
+                       const int bh, const int q0, const int sp, const int splits) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
   const int nq = (int)p.nq;
-  const int q0 = qt * BQ + wave * 16 * QB;
-  const int t0 = sp * per_split;
-  const int nt = (total_tiles - t0) < per_split ? (total_tiles - t0) : per_split;   // >= 1: the host sizes splits so that every pass has keys
-
-  f32x4 o[QB][4], lacc[QB], negm[QB];
-  if constexpr (MODE == 1) {
-    attn16::run_tiles<T, QB, WAVES, 0, VSUM>(p, lds, bh, q0, t0, nt, o, lacc, negm);
-  } else {
-    attn16::run_tiles<T, QB, WAVES, 2, VSUM>(p, lds, bh, q0, t0, nt, o, lacc, negm);
-    bool bad = MODE == 2;
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-      bad = bad || attn16::bad_sum(lacc[qb][0]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bad = bad || attn16::nonfinite(o[qb][dt][r]);
-    }
-    if (__syncthreads_or(bad ? 1 : 0)) attn16::run_tiles<T, QB, WAVES, 0, VSUM>(p, lds, bh, q0, t0, nt, o, lacc, negm);
-  }
-
   const int bq = bh / OVG_H, hh = bh % OVG_H;
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
@@ -376,6 +345,45 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params
       if (p.lse != nullptr && g == 0) p.lse[(int64_t)bh * p.nq_pad + q] = __builtin_amdgcn_logf(lacc[qb][0]) - negm[qb][0];
     }
   }
+}
+
+}  // namespace attn16
+
+// MODE: 0 = speculative anchored softmax + verified fallback, 1 = lazy-rescale only, 2 = forced fallback (tests)
+template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false>   // OCC: minimum waves per SIMD the register allocation must allow
+__global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params p, int nqt, int total_tiles, int splits, int per_split) {
+  static_assert(sizeof(T) == 2, "16-bit types only");
+  constexpr int RB = 128, KT_B = BC * RB, VT_B = OVG_D * RB, BQ = 16 * QB * WAVES;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (KT_B + VT_B)];
+
+  const int tid = threadIdx.x, wave = tid >> 6;
+  // logical id -> (batch entry, key split, q tile), q tile fastest: the workgroups that run side by side on an XCD share
+  // one (entry, split) = one K / V^T range, which with splits is 1 / splits of the head's keys
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = lid % nqt, rest = lid / nqt;
+  const int sp = rest % splits, bh = rest / splits;
+  const int q0 = qt * BQ + wave * 16 * QB;
+  const int t0 = sp * per_split;
+  const int nt = (total_tiles - t0) < per_split ? (total_tiles - t0) : per_split;   // >= 1: the host sizes splits so that every pass has keys
+
+  f32x4 o[QB][4], lacc[QB], negm[QB];
+  if constexpr (MODE == 1) {
+    attn16::run_tiles<T, QB, WAVES, 0, VSUM>(p, lds, bh, q0, t0, nt, o, lacc, negm);
+  } else {
+    attn16::run_tiles<T, QB, WAVES, 2, VSUM>(p, lds, bh, q0, t0, nt, o, lacc, negm);
+    bool bad = MODE == 2;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      bad = bad || attn16::bad_sum(lacc[qb][0]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bad = bad || attn16::nonfinite(o[qb][dt][r]);
+    }
+    if (__syncthreads_or(bad ? 1 : 0)) attn16::run_tiles<T, QB, WAVES, 0, VSUM>(p, lds, bh, q0, t0, nt, o, lacc, negm);
+  }
+
+  attn16::write_out<T, QB>(p, o, lacc, negm, bh, q0, sp, splits);
 }
 
 // Second launch of a split-KV call: out[entry, q, :] = sum_s w_s part[s][entry, q, :] / sum_s w_s, w_s = 2^(lse_s - max lse)
