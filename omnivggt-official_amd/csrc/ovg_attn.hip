@@ -254,7 +254,6 @@ __global__ __launch_bounds__(256) void attn_kernel(ovg_attn_params p, int nqt, i
 }
 
 #include "ovg_attn16.h"
-#include "ovg_attn32.h"
 
 // baseline kernel (all dtypes; the f32 parity path and the in-process reference of the A/B tool)
 template <typename T, int QB>
@@ -299,13 +298,13 @@ Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
   const int64_t units512 = p.BH * ((p.nq + 511) / 512);
   if (v == 0) v = bf16 ? (units512 >= 8 * (int64_t)cus ? 33 : 21) : (p.nq >= 4096 ? 6 : 8);
   pl.variant = v;
-  pl.bq = (v == 33 || v == 41) ? 512 : ((v == 8 || v == 25 || v == 19) ? 128 : 256);
+  pl.bq = (v == 33) ? 512 : ((v == 8 || v == 25 || v == 19) ? 128 : 256);
   pl.total_tiles = total_key_tiles(p);
-  const int slots = (v == 33 || v == 41) ? cus : 2 * cus;
+  const int slots = (v == 33) ? cus : 2 * cus;
   const int64_t units = p.BH * ((p.nq + pl.bq - 1) / pl.bq);
   int splits = 1;
   if (p.kv_splits > 1) splits = p.kv_splits;
-  else if (p.kv_splits == 0 && have_ws && (v == 21 || v == 6 || v == 33 || v == 40 || v == 41)) {
+  else if (p.kv_splits == 0 && have_ws && (v == 21 || v == 6 || v == 33)) {
     // Measured model (profiles/r02_attention_splitkv_ab.txt): a launch of R = units / slots rounds runs at eff(R) = 1 - 0.155 / R^1.2
     // of the many-round rate (0.89 at R = 1.34, 0.95 at 2.7, 0.98 at 5.4: the tail rounds run with fewer co-resident
     // workgroups and are faster than a full one, so the loss is smaller than ceil(R) / R); a split costs ~1.5 key tiles per
@@ -349,22 +348,6 @@ int launch_attn16(const ovg_attn_params& p, const Plan16& pl, hipStream_t st) {
   return OVG_OK;
 }
 
-template <typename T, int WAVES, int MODE>
-int launch_attn32(const ovg_attn_params& p, const Plan16& pl, hipStream_t st) {
-  constexpr int BQ = 64 * WAVES;
-  const int nqt = (int)((p.nq + BQ - 1) / BQ);
-  const dim3 grid((unsigned)(p.BH * nqt * pl.splits)), block(64 * WAVES);
-  OVG_LAUNCH((attn32_kernel<T, WAVES, MODE>), grid, block, 0, st, p, nqt, pl.total_tiles, pl.splits, pl.per_split);
-  OVG_CHECK_LAUNCH();
-  if (pl.splits > 1) {
-    const int64_t total = p.BH * p.nq * 8;
-    const int64_t blocks = (total + 255) / 256;
-    OVG_LAUNCH((attn_split_merge_kernel<T>), dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, p, pl.splits, total);
-    OVG_CHECK_LAUNCH();
-  }
-  return OVG_OK;
-}
-
 // variant (benchmark / test knob; numbers kept from the A/B logs under profiles/):
 //   0 = default: bf16 -> speculative kernel, q tile and split-KV factor from plan16; f16 -> lazy-rescale kernel
 //   1 / 2   baseline kernel, QB = 1 / 2 (never split)
@@ -390,9 +373,6 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
     case 31: return launch_attn16<T, 4, 4, 0, 2, true>(p, pl, st);
     case 32: return launch_attn16<T, 2, 8, 0, 4>(p, pl, st);
     case 33: return launch_attn16<T, 4, 8, 0, 2>(p, pl, st);
-    case 40: return launch_attn32<T, 4, 0>(p, pl, st);            // 32 x 32 x 16 MFMA formulation, 256-row q tiles
-    case 41: return launch_attn32<T, 8, 0>(p, pl, st);            // ... 512-row q tiles (1 workgroup per CU)
-    case 42: return launch_attn32<T, 4, 2>(p, pl, st);            // ... fallback forced (tests)
     default: return OVG_E_ARG;
   }
 }
