@@ -90,10 +90,9 @@ int ovg_layernorm(const ovg_layernorm_params*, void* stream);
  *                   (patch_embed.py:75-77 + vision_transformer.py:220-224)
  * ------------------------------------------------------------------ */
 enum { OVG_EPI_STORE = 0, OVG_EPI_GELU = 1, OVG_EPI_RES = 2, OVG_EPI_PATCH = 3 };
-/* workgroup tile of the GEMM kernels: 128 x 128 (4 waves, register-staged, up to 3 workgroups per CU), 256 x 256 (8 waves,
- * LDS-DMA ring with ping-pong wave groups, 1 workgroup per CU, 16-bit dtypes) or 128(n) x 256(m) (4 waves, LDS-DMA ring,
- * 2 workgroups per CU, 16-bit dtypes); AUTO picks by shape (ovg_gemm.hip: choose_256) */
-enum { OVG_TILE_AUTO = 0, OVG_TILE_128 = 1, OVG_TILE_256 = 2, OVG_TILE_128x256 = 3 };
+/* workgroup tile of the GEMM kernels: 128 x 128 (4 waves, register-staged, up to 3 workgroups per CU) or 256 x 256 (8 waves,
+ * LDS-DMA ring with ping-pong wave groups, 1 workgroup per CU, 16-bit dtypes); AUTO picks by shape (ovg_gemm.hip: choose_256) */
+enum { OVG_TILE_AUTO = 0, OVG_TILE_128 = 1, OVG_TILE_256 = 2 };
 typedef struct {
   const void* x; int64_t ldx;
   const void* w; int64_t ldw;
@@ -106,7 +105,7 @@ typedef struct {
   const float* inject; int64_t inj_period;   /* inject may be NULL */
   /* PATCH */
   const float* table; int64_t p0; int64_t p1; int64_t row_off;
-  int tile;   /* OVG_TILE_AUTO (shape heuristic), OVG_TILE_128, OVG_TILE_256 (16-bit dtypes, N % 256 == 0) or OVG_TILE_128x256 (16-bit dtypes); an impossible request is OVG_E_ARG */
+  int tile;   /* OVG_TILE_AUTO (shape heuristic), OVG_TILE_128 or OVG_TILE_256 (16-bit dtypes, N % 256 == 0); an impossible request is OVG_E_ARG */
 } ovg_linear_params;
 int ovg_linear(const ovg_linear_params*, void* stream);
 

@@ -505,39 +505,6 @@ __global__ __launch_bounds__(512) void qkv256_kernel(ovg_qkv_params p, int nt_be
   }
 }
 
-// 128(n) x 256(m) tiles, two workgroups per CU (ovg_gemm256.h: g2)
-template <typename T, int EPI, bool OUT_F32>
-__global__ __launch_bounds__(256, 2) void linear2x_kernel(ovg_linear_params p, int ntiles_n) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds256[];
-  const int M = (int)p.M, N = (int)p.N, K = (int)p.K;
-  int tm, tn;
-  tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + g256::g2::BMA - 1) / g256::g2::BMA, ntiles_n, tm, tn);
-  const int m0 = tm * g256::g2::BMA, n0 = tn * g256::g2::BNA;
-  f32x4 acc[4][8];
-  g256::g2::mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds256, acc);
-  const int wave = threadIdx.x >> 6;
-  linear_epilogue<T, EPI, OUT_F32, 8>(p, acc, m0 + (wave >> 1) * 128, n0 + (wave & 1) * 64);
-}
-
-template <typename T>
-__global__ __launch_bounds__(256, 2) void qkv2x_kernel(ovg_qkv_params p, int nt_begin, int nt_count) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds256[];
-  constexpr int N = 3 * OVG_C, K = OVG_C;
-  const int M = (int)p.M;
-  int tm, tn;
-  tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + g256::g2::BMA - 1) / g256::g2::BMA, nt_count, tm, tn);
-  const int m0 = tm * g256::g2::BMA, n0 = (nt_begin + tn) * g256::g2::BNA;
-  const int wave = threadIdx.x >> 6;
-  f32x4 acc[4][8];
-  if (n0 >= 2 * OVG_C) {                                   // V^T tile (workgroup-uniform): transposed accumulators
-    g256::g2::mainloop<T, true>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds256, acc);
-    v_epilogue<T, 8>(p, acc, m0 + (wave >> 1) * 128, n0 + (wave & 1) * 64);
-  } else {                                                 // RoPE table from global memory (L1 / L2): the second workgroup hides it
-    g256::g2::mainloop<T, false>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds256, acc);
-    qk_epilogue<T, 8>(p, acc, m0 + (wave >> 1) * 128, n0 + (wave & 1) * 64, p.rope_cos, p.rope_sin);
-  }
-}
-
 template <typename KernelT>
 int allow_big_lds(KernelT kernel, int bytes = g256::LDS_BYTES) {     // once per kernel: opt in to > 64 KB of dynamic LDS
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? OVG_OK : OVG_E_LAUNCH;
@@ -582,25 +549,6 @@ int launch_linear256_one(const ovg_linear_params& p, hipStream_t st) {
   OVG_CHECK_LAUNCH();
   return OVG_OK;
 }
-template <typename T, int EPI, bool OUT_F32>
-int launch_linear2x_one(const ovg_linear_params& p, hipStream_t st) {
-  static const int ok = allow_big_lds(linear2x_kernel<T, EPI, OUT_F32>, g256::g2::LDS_BYTES_A);
-  if (ok != OVG_OK) return ok;
-  const int mt = (int)((p.M + g256::g2::BMA - 1) / g256::g2::BMA), nt = (int)(p.N / g256::g2::BNA);
-  OVG_LAUNCH((linear2x_kernel<T, EPI, OUT_F32>), dim3(mt * nt), dim3(256), g256::g2::LDS_BYTES_A, st, p, nt | (TILE_GROUP256 << 16));
-  OVG_CHECK_LAUNCH();
-  return OVG_OK;
-}
-template <typename T>
-int launch_linear2x(const ovg_linear_params& p, hipStream_t st) {
-  switch (p.epilogue) {
-    case OVG_EPI_STORE: return p.out_f32 ? launch_linear2x_one<T, OVG_EPI_STORE, true>(p, st) : launch_linear2x_one<T, OVG_EPI_STORE, false>(p, st);
-    case OVG_EPI_GELU: return launch_linear2x_one<T, OVG_EPI_GELU, false>(p, st);
-    case OVG_EPI_RES: return launch_linear2x_one<T, OVG_EPI_RES, true>(p, st);
-    case OVG_EPI_PATCH: return launch_linear2x_one<T, OVG_EPI_PATCH, true>(p, st);
-    default: return OVG_E_ARG;
-  }
-}
 template <typename T>
 int launch_linear256(const ovg_linear_params& p, hipStream_t st) {
   switch (p.epilogue) {
@@ -619,12 +567,11 @@ int launch_linear256(const ovg_linear_params& p, hipStream_t st) {
 // the denser 256 x 256 GEMMs run 9 % slower (0.533 vs 0.488 ms: the chip is power-limited, rocprofv3 shows the GEMMs at
 // 1.8-1.9 GHz and attention at 2.1-2.2 GHz, and the GEMMs' own in-situ gain shrinks with cold L2s and one workgroup per
 // CU). So the 256 x 256 kernels are used from M >= 32 768 rows (24 views), where they are worth +2 % on the 64-view forward.
-// Returns 1 = use 256^2, 2 = 128(n) x 256(m) at two workgroups per CU, 0 = use 128^2, -1 = the caller forced a tile this shape / dtype cannot run.
+// Returns 1 = use 256^2, 0 = use 128^2, -1 = the caller forced a tile this shape / dtype cannot run.
 int choose_256(int tile, bool sixteen_bit, int64_t M, int64_t N, int64_t K, bool light_epilogue_or_long_k) {
   const bool legal = sixteen_bit && N % g256::BN2 == 0 && K % 32 == 0;
   if (tile == OVG_TILE_128) return 0;
   if (tile == OVG_TILE_256) return legal ? 1 : -1;
-  if (tile == OVG_TILE_128x256) return (sixteen_bit && K % 32 == 0) ? 2 : -1;
   if (tile != OVG_TILE_AUTO) return -1;
   if (!legal || !light_epilogue_or_long_k || M < 32768) return 0;
   return 1;
@@ -635,7 +582,6 @@ int launch_linear(const ovg_linear_params& p, hipStream_t st) {
   const int big = choose_256(p.tile, sizeof(T) == 2, p.M, p.N, p.K, p.epilogue != OVG_EPI_RES || p.K >= 2048);
   if (big < 0) return OVG_E_ARG;
   if constexpr (sizeof(T) == 2) {
-    if (big == 2) return launch_linear2x<T>(p, st);
     if (big) return launch_linear256<T>(p, st);
   }
   return launch_linear128<T>(p, st);
@@ -686,24 +632,6 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int big = choose_256(p->tile, p->dtype != OVG_F32, p->M, (p->part == 0 ? 3 : (p->part == 1 ? 2 : 1)) * OVG_C, OVG_C, true);
   if (big < 0) return OVG_E_ARG;
-  if (big == 2) {
-    const int q_t = OVG_C / g256::g2::BNA, all_t = 3 * OVG_C / g256::g2::BNA;
-    const int ntb = p->part == 1 ? q_t : 0;
-    const int ntc = p->part == 0 ? all_t : (p->part == 1 ? all_t - q_t : q_t);
-    const dim3 grid2((unsigned)(((p->M + g256::g2::BMA - 1) / g256::g2::BMA) * ntc));
-    const int ntg2 = ntc | (TILE_GROUP256 << 16);
-    if (p->dtype == OVG_BF16) {
-      static const int ok = allow_big_lds(qkv2x_kernel<bf16_t>, g256::g2::LDS_BYTES_A);
-      if (ok != OVG_OK) return ok;
-      OVG_LAUNCH((qkv2x_kernel<bf16_t>), grid2, dim3(256), g256::g2::LDS_BYTES_A, st, *p, ntb, ntg2);
-    } else {
-      static const int ok = allow_big_lds(qkv2x_kernel<f16_t>, g256::g2::LDS_BYTES_A);
-      if (ok != OVG_OK) return ok;
-      OVG_LAUNCH((qkv2x_kernel<f16_t>), grid2, dim3(256), g256::g2::LDS_BYTES_A, st, *p, ntb, ntg2);
-    }
-    OVG_CHECK_LAUNCH();
-    return OVG_OK;
-  }
   if (big) {
     const int q_t = OVG_C / g256::BN2, all_t = 3 * OVG_C / g256::BN2;
     const int ntb = p->part == 1 ? q_t : 0;

@@ -151,97 +151,4 @@ OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict_
 
 
 
-// ---------------------------------------------------------------------------------------------------------
-// 128(n) x 256(m) tile on 4 waves, TWO workgroups per CU (r02). The 256 x 256 loop above runs its main loop at ~1.3 PFLOP/s
-// but owns the CU alone, so its epilogue (VALU: GELU / q-k-norm / RoPE; memory: the f32 residual round trip) runs with the
-// matrix pipe idle -- 25-45 % of a K = 1024 tile (profiles/r02_gemm_epilogue_mlp.txt). Here two independent workgroups
-// share a CU: 72 KB of LDS each (3-slot ring of 24 KB k-stages: W 128 x 64 B + X 256 x 64 B), 4 waves of 64(n) x 128(m)
-// (the same acc[4][8] wave tile, so the same epilogue functions), <= 256 VGPRs. Nothing synchronises the two, so one's
-// epilogue and barrier waits fall under the other's MFMA sections. Per stage and wave: 6 DMA instructions (1 KB each),
-// 12 ds_read_b128, 32 MFMAs, ONE barrier:
-//     w(t): counted vmcnt -- stage t landed (stage t + 1 may still be in flight) | barrier | DMA of stage t + 2 into the slot
-//     stage t - 1 was read from | fragments of stage t | 32 MFMAs
-//   RAW: a wave's own share of stage t is covered by w(t), everybody else's by the barrier behind it.
-//   WAR: stage t + 2 overwrites the slot of stage t - 1, whose fragment reads every wave retired (lgkmcnt(0) before its
-//        MFMAs of t - 1) before it reached this barrier.
-// Same 64-byte-row LDS image and swizzle as above (slot = chunk ^ swz64(row), applied to the DMA source and the reads).
-namespace g2 {
-constexpr int BMA = 256, BNA = 128, SLOTS_A = 3;
-constexpr int W_TILE_A = BNA * ROWB, X_TILE_A = BMA * ROWB, STAGE_A = W_TILE_A + X_TILE_A;
-constexpr int LDS_BYTES_A = SLOTS_A * STAGE_A;              // 73 728
-
-template <typename T, bool SWAP = false>
-OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict__ W, int64_t ldw,
-                      int M, int N, int K, int m0, int n0, unsigned char* lds, f32x4 (&acc)[4][8]) {
-  static_assert(sizeof(T) == 2, "16-bit operands");
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave & 1, wm = wave >> 1;
-  const int g = lane >> 4, lr = lane & 15;
-
-  // DMA sources: wave w stages W rows [32w, 32w + 32) and X rows [64w, 64w + 64), 16 rows per instruction
-  const unsigned char* wg[2];
-  const unsigned char* xg[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int xrow = wave * 64 + i * 16 + (lane >> 2);
-    int xr = m0 + xrow; xr = xr < M ? xr : M - 1;
-    xg[i] = reinterpret_cast<const unsigned char*>(X + (int64_t)xr * ldx) + ((lane & 3) ^ swz64(xrow)) * 16;
-    if (i < 2) {
-      const int wrow = wave * 32 + i * 16 + (lane >> 2);
-      int wr = n0 + wrow; wr = wr < N ? wr : N - 1;
-      wg[i] = reinterpret_cast<const unsigned char*>(W + (int64_t)wr * ldw) + ((lane & 3) ^ swz64(wrow)) * 16;
-    }
-  }
-  auto stage = [&](int kt, int slot) {
-    unsigned char* wb = lds + slot * STAGE_A + wave * 32 * ROWB;             // wave-uniform destinations
-    unsigned char* xb = lds + slot * STAGE_A + W_TILE_A + wave * 64 * ROWB;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wg[i] + (int64_t)kt * ROWB), (lptr_t)(wb + i * 16 * ROWB), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(xg[i] + (int64_t)kt * ROWB), (lptr_t)(xb + i * 16 * ROWB), 16, 0, 0);
-  };
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = (K * 2) / ROWB;
-  const int frag_off = lr * ROWB + (g ^ swz64(lr)) * 16;
-  const int w_off = wn * 64 * ROWB + frag_off, x_off = W_TILE_A + wm * 128 * ROWB + frag_off;
-  u32x4 a[4], b[8];
-
-  stage(0, 0);
-  if (nk > 1) stage(1, 1);
-  int slot = 0;
-  for (int t = 0; t < nk; ++t) {
-    if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // w(t): everything but stage t + 1's six instructions
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                          // NOT __syncthreads: its fence would drain vmcnt to 0
-    if (t + 2 < nk) stage(t + 2, slot == 0 ? 2 : slot - 1);               // (t + 2) % 3 == (t - 1) % 3
-    const unsigned char* base = lds + slot * STAGE_A;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const u32x4*>(base + w_off + i * 16 * ROWB);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) b[i] = *reinterpret_cast<const u32x4*>(base + x_off + i * 16 * ROWB);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int mt = 0; mt < 8; ++mt) {
-        if constexpr (SWAP) TT<T>::mma(acc[nt][mt], b[mt], a[nt]);
-        else TT<T>::mma(acc[nt][mt], a[nt], b[mt]);
-      }
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    slot = slot == 2 ? 0 : slot + 1;
-  }
-}
-}  // namespace g2
-
 }  // namespace g256

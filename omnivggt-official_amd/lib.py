@@ -15,7 +15,7 @@ EPI_STORE, EPI_GELU, EPI_RES, EPI_PATCH = 0, 1, 2, 3
 OVG_MAX_SEG = 8
 KV_TILE = 64
 ABI_VERSION = 4
-TILE_AUTO, TILE_128, TILE_256, TILE_128x256 = 0, 1, 2, 3
+TILE_AUTO, TILE_128, TILE_256 = 0, 1, 2
 
 ERRORS = {0: "OVG_OK", -1: "OVG_E_ARG", -2: "OVG_E_DTYPE", -3: "OVG_E_LAUNCH", -4: "OVG_E_UNSUPPORTED"}
 

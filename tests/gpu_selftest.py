@@ -523,9 +523,7 @@ def test_gemm256(quick, tile=None, auto_is=True):
         out = torch.zeros(3 * p1, N, device=DEV)
         ops.linear(x.to(DEV), w.to(DEV), bias.to(DEV), dt, epilogue=L.EPI_PATCH, out=out, table=table.to(DEV), p0=p0, p1=p1, row_off=5, tile=T256)
         report("gemm256_patch_%s" % name, out, ref, 2e-5)
-        # an illegal forced tile is refused, not silently replaced (the 128 x 256 tile accepts every N the 128^2 one does)
-        if T256 != L.TILE_256:
-            continue
+        # an illegal forced tile is refused, not silently replaced
         try:
             ops.linear(x.to(DEV)[:, :640], w.to(DEV)[:128], None, dt, tile=T256)
             results.append({"name": "gemm256_illegal_n_refused_" + name, "ok": False, "rel": float("nan")})
@@ -761,7 +759,7 @@ def main():
     print(L.load().ovg_build_info().decode(), torch.cuda.get_device_name(0), flush=True)
     tests = {"probe": test_probe, "layernorm": test_layernorm, "linear": lambda: test_linear(args.quick), "qkv": lambda: test_qkv(args.quick),
              "attn": lambda: test_attn(args.quick), "embed": test_embed, "block": lambda: test_block(args.quick),
-             "heads": lambda: test_heads(args.quick), "gemm256": lambda: test_gemm256(args.quick), "gemm2x": lambda: test_gemm256(args.quick, L.TILE_128x256, False), "attn_big": lambda: test_attn_big(args.quick),
+             "heads": lambda: test_heads(args.quick), "gemm256": lambda: test_gemm256(args.quick), "attn_big": lambda: test_attn_big(args.quick),
              "lse_merge": test_attn_lse_merge}
     for name, fn in tests.items():
         if args.only and name not in args.only.split(","):

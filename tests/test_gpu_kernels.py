@@ -67,12 +67,6 @@ def test_gemm256_kernels_every_epilogue_ragged_m():
     _assert_clean()
 
 
-def test_gemm_128x256_two_workgroups_per_cu_every_epilogue_ragged_m():
-    """linear2x_kernel / qkv2x_kernel (OVG_TILE_128x256): the same checks as the 256 x 256 kernels."""
-    st.test_gemm256(False, L.TILE_128x256, False)
-    _assert_clean()
-
-
 def test_global_attention_at_bench_key_counts():
     """N = 10 992 / 21 984 in full, N = 87 936 on sampled rows: the launches the bench times."""
     st.test_attn_big(False)
