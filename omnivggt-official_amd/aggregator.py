@@ -430,12 +430,14 @@ class ZeroAggregator(nn.Module):
         x[:, : self.pose_hidden_dim] = enc.reshape(B * Sc, -1)
         emb = ops.linear(x.to(device), pk["pose_w"], pk["pose_b"], torch.float32, out_f32=True)   # [B*Sc, G*1024]
         rows = (torch.arange(B).unsqueeze(1) * S + idx.unsqueeze(0)).reshape(-1).to(device)
-        tables = []
+        # only the camera views go through the adapters (same kernel, same k order as a full [K,1024] GEMM would use for
+        # those rows); every other row is Linear(0) = bias exactly.  One table buffer, one scatter.
+        tables = torch.stack(pk["adapt_b"]).unsqueeze(1).repeat(1, K, 1)                          # [G,K,1024]
+        out = torch.empty(G, B * Sc, C, device=device)
         for i in range(G):
-            full = torch.zeros(K, C, device=device)
-            full[rows] = emb[:, i * C:(i + 1) * C]
-            tables.append(ops.linear(full, pk["adapt_w"][i], pk["adapt_b"][i], torch.float32, out_f32=True))
-        return tables
+            ops.linear(emb[:, i * C:(i + 1) * C], pk["adapt_w"][i], pk["adapt_b"][i], torch.float32, out=out[i], out_f32=True)
+        tables[:, rows] = out
+        return list(tables.unbind(0))
 
     def depth_tokens(self, pk, depth, mask, depth_gt_index, B, S, device):
         """(depth_tok [B*n*P0,1024] f32 or None, depth_row int32 [B*S])
