@@ -271,7 +271,10 @@ def test_packed_weights_roundtrip(tmp_path):
     path = str(tmp_path / "packed.safetensors")
     m.save_packed(path)
     full = sum(v.numel() * 4 for v in sd.values())
-    assert os.path.getsize(path) < 0.62 * full
+    gemm = sum(v.numel() * 4 for k, v in sd.items() if k.startswith("aggregator.") and
+               k.endswith(("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")))
+    # the block GEMM weights are stored in 16 bits (the heads and all vectors stay f32): the file saves half of THEIR bytes
+    assert os.path.getsize(path) < full - 0.45 * gemm
     m2 = OmniVGGT.from_packed(path)
     assert m2.aggregator.frame_blocks[0].attn.qkv.weight.is_meta and m2.aggregator.compute_dtype == torch.bfloat16
     toks, start = run_agg(m2, S, dgi, cgi)
