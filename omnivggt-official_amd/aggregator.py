@@ -326,6 +326,9 @@ class ZeroAggregator(nn.Module):
         """One-time pre-pack after load_state_dict: GEMM weights -> compute dtype, the rest f32.
         sd: use this state dict instead of the module's parameters -- export_packed() output read back from disk, whose
         GEMM weights are already in the compute dtype (and the two Conv2d patch weights already 2-D, zero padded)."""
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:          # "cuda" and "cuda:<current>" are the same pack
+            device = torch.device("cuda", torch.cuda.current_device())
         if sd is None and self._packed is not None and self._packed["device"] == device and self._packed["dtype"] == self.compute_dtype:
             return self._packed
         L.require_gpu()
