@@ -38,7 +38,7 @@ extern "C" {
  * 4: per-call GEMM tile selector (`tile`) replacing the process-global debug setter of ABI 3, optional
  *    log-sum-exp output of ovg_flash_attn + ovg_attn_merge (two-launch local-first sharded attention),
  *    ovg_block_workspace_bytes, ovg_pack_weights, split-KV attention (kv_splits / ws_part / ws_lse, ovg_attn_plan) */
-#define OVG_ABI_VERSION 4
+#define OVG_ABI_VERSION 5
 
 enum { OVG_BF16 = 0, OVG_F16 = 1, OVG_F32 = 2 };
 
@@ -413,6 +413,43 @@ typedef struct {
   const void* x; int64_t n_pad; void* y; int64_t ldy; int64_t n; int heads; int dtype;
 } ovg_heads_to_tokens_params;
 int ovg_heads_to_tokens(const ovg_heads_to_tokens_params*, void* stream);
+
+/* ------------------------------------------------------------------
+ * Camera head: replaces CameraHead.forward / trunk_fn, omnivggt/heads/camera_head.py:84-154, for
+ * one batch element: S camera tokens (row m of `tokens`, 2048 f32, row stride ld_tokens elements: the slot-0 token of
+ * every view in the LAST aggregator layer, camera_head.py:96-100) -> out [iters][S][9] f32, the activated pose
+ * encodings of every refinement round (absT_quaR_FoV: translation and quaternion linear, field of view ReLU,
+ * heads/head_act.py:12-35). One call issues every launch of every round; nothing is read back in between.
+ *   GEMM weights (mod_w [6144,2048], blk[i].qkv_w [6144,2048], proj_w [2048,2048], fc1_w [8192,2048],
+ *   fc2_w [2048,8192], pb1_w [1024,2048]) in `dtype` (OVG_BF16 / OVG_F16; nn.Linear layout, K contiguous, 16-byte
+ *   aligned); every vector, the 9-wide embed_pose [2048,9] and pose_branch.fc2 [9,1024] matrices and all activations
+ *   that carry state (residual stream, statistics, softmax, pose) f32. OVG_F32 -> OVG_E_UNSUPPORTED (the f32 parity
+ *   mode keeps the PyTorch module). dim must be 2048, heads 16 (head dim 128), trunk_depth <= OVG_CAMERA_MAX_TRUNK,
+ *   S <= 4096. ws: caller-owned scratch of >= ovg_camera_head_workspace_bytes(S, dtype) bytes (returns -1 on bad args).
+ * ------------------------------------------------------------------ */
+#define OVG_CAMERA_MAX_TRUNK 4
+typedef struct {
+  const float *n1_w, *n1_b, *n2_w, *n2_b, *ls1, *ls2;
+  const void* qkv_w; const float* qkv_b;
+  const void* proj_w; const float* proj_b;
+  const void* fc1_w; const float* fc1_b;
+  const void* fc2_w; const float* fc2_b;
+} ovg_camera_block_weights;
+typedef struct {
+  const float* tokens; int64_t ld_tokens;
+  int32_t S; int32_t iters; int32_t dtype; int32_t trunk_depth; int32_t dim; int32_t heads;
+  const float *token_norm_w, *token_norm_b, *trunk_norm_w, *trunk_norm_b;
+  const float* empty_pose;
+  const float *embed_w, *embed_b;
+  const void* mod_w; const float* mod_b;
+  ovg_camera_block_weights blk[OVG_CAMERA_MAX_TRUNK];
+  const void* pb1_w; const float* pb1_b;
+  const float *pb2_w, *pb2_b;
+  void* ws; int64_t ws_bytes;
+  float* out;
+} ovg_camera_head_params;
+int64_t ovg_camera_head_workspace_bytes(int32_t S, int32_t dtype);
+int ovg_camera_head(const ovg_camera_head_params*, void* stream);
 
 /* MFMA lane-map probe (diagnostics; tools/selftest.py): fills out[64*4] with
  * acc of one 16x16 MFMA for dtype given raw 16-byte A/B fragments per lane. */

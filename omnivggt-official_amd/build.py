@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libomnivggt_hip.so")
-SOURCES = ["ovg_gemm.hip", "ovg_attn.hip", "ovg_elem.hip", "ovg_block.hip", "ovg_head.hip"]
+SOURCES = ["ovg_gemm.hip", "ovg_attn.hip", "ovg_elem.hip", "ovg_block.hip", "ovg_head.hip", "ovg_camhead.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 # attention: no NaN can occur on valid inputs (masked scores are -inf, never inf-inf), and without
 # this hipcc inserts a canonicalising v_max before every fmaxf on an MFMA output (64 VALU / tile)
@@ -74,7 +74,7 @@ def build(force=False, verbose=True):
             sys.stderr.write(r.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(cc, SOURCES))
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs], capture_output=True, text=True)
     if r.returncode != 0:

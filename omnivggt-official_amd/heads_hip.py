@@ -156,3 +156,64 @@ class HipDPTHead:
         y = ops.upsample(y, ph * ps, pw * ps, dtype, pos=self._postab(128, ph * ps, pw * ps, W, H, dev))
         hmap = ops.conv(y, P["oc2a"][0], P["oc2a"][1], dtype, 32, ksize=3, relu=True, out_f32=True)
         return ops.dpt_out(hmap, P["oc2b"][0], P["oc2b"][1], head.activation)
+
+
+class HipCameraHead:
+    """Camera head on the `ovg_camera_head` entry (csrc/ovg_camhead.hip): the iterative pose regressor of
+    heads/camera_head.py:84-154 with its six kinds of GEMM as split-K weight streams on the MFMA, in the 16-bit
+    compute dtype; the parameters stay in the wrapped `heads.CameraHead` (same state-dict keys) and are re-packed
+    on first use per device / dtype. One C call per batch element issues all ~165 launches of the four rounds."""
+
+    def __init__(self, head):
+        self.head = head
+        self._packed = None
+        self._key = None
+        self._ws = {}
+
+    def _pack(self, dtype, device):
+        h = self.head
+        cv = lambda w: w.detach().to(device=device, dtype=dtype).contiguous()
+        f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+        mod = h.poseLN_modulation[1]
+        P = {"token_norm_w": f32(h.token_norm.weight), "token_norm_b": f32(h.token_norm.bias),
+             "trunk_norm_w": f32(h.trunk_norm.weight), "trunk_norm_b": f32(h.trunk_norm.bias),
+             "empty_pose": f32(h.empty_pose_tokens.reshape(-1)), "embed_w": f32(h.embed_pose.weight), "embed_b": f32(h.embed_pose.bias),
+             "mod_w": cv(mod.weight), "mod_b": f32(mod.bias),
+             "pb1_w": cv(h.pose_branch.fc1.weight), "pb1_b": f32(h.pose_branch.fc1.bias),
+             "pb2_w": f32(h.pose_branch.fc2.weight), "pb2_b": f32(h.pose_branch.fc2.bias),
+             "heads": h.trunk[0].attn.heads, "blocks": []}
+        for blk in h.trunk:
+            P["blocks"].append({"n1_w": f32(blk.norm1.weight), "n1_b": f32(blk.norm1.bias), "n2_w": f32(blk.norm2.weight), "n2_b": f32(blk.norm2.bias),
+                                "ls1": f32(blk.ls1.gamma), "ls2": f32(blk.ls2.gamma),
+                                "qkv_w": cv(blk.attn.qkv.weight), "qkv_b": f32(blk.attn.qkv.bias),
+                                "proj_w": cv(blk.attn.proj.weight), "proj_b": f32(blk.attn.proj.bias),
+                                "fc1_w": cv(blk.mlp.fc1.weight), "fc1_b": f32(blk.mlp.fc1.bias),
+                                "fc2_w": cv(blk.mlp.fc2.weight), "fc2_b": f32(blk.mlp.fc2.bias)})
+        return P
+
+    def _weights(self, dtype, device):
+        key = (dtype, str(device), tuple((q.data_ptr(), q._version) for q in self.head.parameters()))
+        if self._key != key:
+            self._packed, self._key = self._pack(dtype, device), key
+        return self._packed
+
+    def repack(self):
+        self._key = None
+
+    def __call__(self, aggregated_tokens_list, num_iterations=4, dtype=torch.bfloat16):
+        """-> list of `num_iterations` tensors (B, S, 9), like CameraHead.forward."""
+        toks = aggregated_tokens_list[-1]
+        B, S = toks.shape[:2]
+        W = self._weights(dtype, toks.device)
+        outs = []
+        for b in range(B):
+            cam = toks[b, :, 0]                                        # [S, 2C] f32 view, row stride = tokens_per_view * 2C
+            if cam.stride(-1) != 1:
+                cam = cam.contiguous()
+            key = (S, dtype, str(toks.device))
+            if key not in self._ws:
+                self._ws.clear()
+                self._ws[key] = torch.empty(ops.camera_head_workspace_bytes(S, dtype), device=toks.device, dtype=torch.uint8)
+            outs.append(ops.camera_head(cam, W, dtype, iters=num_iterations, ws=self._ws[key]))
+        full = torch.stack(outs, dim=1)                                # [iters, B, S, 9]
+        return [full[i] for i in range(num_iterations)]

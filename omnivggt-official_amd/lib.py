@@ -14,7 +14,7 @@ OVG_BF16, OVG_F16, OVG_F32 = 0, 1, 2
 EPI_STORE, EPI_GELU, EPI_RES, EPI_PATCH = 0, 1, 2, 3
 OVG_MAX_SEG = 8
 KV_TILE = 64
-ABI_VERSION = 4
+ABI_VERSION = 5
 TILE_AUTO, TILE_128, TILE_256 = 0, 1, 2
 
 ERRORS = {0: "OVG_OK", -1: "OVG_E_ARG", -2: "OVG_E_DTYPE", -3: "OVG_E_LAUNCH", -4: "OVG_E_UNSUPPORTED"}
@@ -145,6 +145,21 @@ class UnprojectParams(C.Structure):
     _fields_ = [("depth", vp), ("cam", vp), ("out", vp), ("S", i64), ("H", i32), ("W", i32)]
 
 
+CAMERA_MAX_TRUNK = 4
+
+
+class CameraBlockWeights(C.Structure):
+    _fields_ = [("n1_w", vp), ("n1_b", vp), ("n2_w", vp), ("n2_b", vp), ("ls1", vp), ("ls2", vp),
+                ("qkv_w", vp), ("qkv_b", vp), ("proj_w", vp), ("proj_b", vp), ("fc1_w", vp), ("fc1_b", vp), ("fc2_w", vp), ("fc2_b", vp)]
+
+
+class CameraHeadParams(C.Structure):
+    _fields_ = [("tokens", vp), ("ld_tokens", i64), ("S", i32), ("iters", i32), ("dtype", i32), ("trunk_depth", i32), ("dim", i32), ("heads", i32),
+                ("token_norm_w", vp), ("token_norm_b", vp), ("trunk_norm_w", vp), ("trunk_norm_b", vp), ("empty_pose", vp),
+                ("embed_w", vp), ("embed_b", vp), ("mod_w", vp), ("mod_b", vp), ("blk", CameraBlockWeights * CAMERA_MAX_TRUNK),
+                ("pb1_w", vp), ("pb1_b", vp), ("pb2_w", vp), ("pb2_b", vp), ("ws", vp), ("ws_bytes", i64), ("out", vp)]
+
+
 # every entry point of include/omnivggt_hip.h: name -> (restype, argtypes)
 SYMBOLS = {
     "ovg_abi_version": (i32, []),
@@ -172,6 +187,8 @@ SYMBOLS = {
     "ovg_attn_plan": (i32, [C.POINTER(AttnParams), C.POINTER(AttnPlanOut)]),
     "ovg_block_workspace_bytes": (i32, [C.POINTER(BlockParams), C.POINTER(BlockWorkspace)]),
     "ovg_pack_weights": (i32, [C.POINTER(PackWeightsParams), vp]),
+    "ovg_camera_head": (i32, [C.POINTER(CameraHeadParams), vp]),
+    "ovg_camera_head_workspace_bytes": (i64, [i32, i32]),
 }
 
 

@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from .aggregator import ZeroAggregator
 from .heads import CameraHead, DPTHead
-from .heads_hip import HipDPTHead
+from .heads_hip import HipCameraHead, HipDPTHead
 
 try:  # the reference mixes in huggingface_hub.PyTorchModelHubMixin (omnivggt.py:3,10)
     from huggingface_hub import PyTorchModelHubMixin as _HubMixin
@@ -44,6 +44,14 @@ class OmniVGGT(nn.Module, _HubMixin):
         # HIP front ends of the two DPT heads; plain objects (not sub-modules): the parameters and the
         # state-dict keys stay those of point_head / depth_head
         self._hip_dpt = {"point": HipDPTHead(self.point_head), "depth": HipDPTHead(self.depth_head)}
+        self._hip_cam = HipCameraHead(self.camera_head)
+
+    def _camera(self, cam_tokens):
+        dt = self.aggregator.compute_dtype
+        toks = cam_tokens[-1]
+        if self.hip_heads and dt in (torch.bfloat16, torch.float16) and toks.is_cuda and toks.shape[1] <= 4096:
+            return self._hip_cam(cam_tokens, dtype=dt)
+        return self.camera_head(cam_tokens)
 
     def _dpt(self, which, head, tokens, imgs32, patch_start_idx):
         dt = self.aggregator.compute_dtype
@@ -136,7 +144,7 @@ class OmniVGGT(nn.Module, _HubMixin):
                 cam_tokens = [shard.gather_views(tokens[-1][:, :, :1].contiguous(), parts)]
                 imgs32 = imgs32[:, lo:hi]
             if self.camera_head is not None:
-                poses = self.camera_head(cam_tokens)
+                poses = self._camera(cam_tokens)
                 out["pose_enc"], out["pose_enc_list"] = poses[-1], poses
             if self.depth_head is not None:
                 out["depth"], out["depth_conf"] = self._dpt("depth", self.depth_head, tokens, imgs32, patch_start_idx)

@@ -317,6 +317,41 @@ def dpt_out(h, w2, b2, activation):
     return val, conf
 
 
+def camera_head_workspace_bytes(S, dtype):
+    n = L.load().ovg_camera_head_workspace_bytes(S, L.dtype_code(dtype))
+    if n < 0:
+        raise L.OvgError("ovg_camera_head_workspace_bytes: unsupported (S=%d, dtype=%s)" % (S, dtype))
+    return int(n)
+
+
+def camera_head(tokens, W, dtype, iters=4, ws=None):
+    """Whole CameraHead.forward (camera_head.py:84-154) of one batch element in one call.
+    tokens: f32 [S, 2048] view of the camera tokens (row stride allowed, e.g. out[-1][b, :, 0]); W: packed weights
+    (heads_hip.HipCameraHead._pack: GEMM matrices in `dtype`, everything else f32); -> [iters, S, 9] f32."""
+    _chk_dev(tokens, ws)
+    S = tokens.shape[0]
+    if tokens.dtype != torch.float32 or tokens.shape[1] != 2048 or tokens.stride(1) != 1:
+        raise L.OvgError("camera_head: tokens must be f32 [S, 2048] with unit inner stride")
+    need = camera_head_workspace_bytes(S, dtype)
+    if ws is None or ws.numel() * ws.element_size() < need:
+        ws = torch.empty(need, device=tokens.device, dtype=torch.uint8)
+    out = torch.empty(iters, S, 9, device=tokens.device, dtype=torch.float32)
+    p = L.CameraHeadParams()
+    p.tokens, p.ld_tokens, p.S, p.iters, p.dtype = L.ptr(tokens), tokens.stride(0), S, iters, L.dtype_code(dtype)
+    p.trunk_depth, p.dim, p.heads = len(W["blocks"]), 2048, W["heads"]
+    for name in ("token_norm_w", "token_norm_b", "trunk_norm_w", "trunk_norm_b", "empty_pose", "embed_w", "embed_b", "mod_w", "mod_b",
+                 "pb1_w", "pb1_b", "pb2_w", "pb2_b"):
+        _chk_dev(W[name])
+        setattr(p, name, L.ptr(W[name]))
+    for i, blk in enumerate(W["blocks"]):
+        for name, _ in L.CameraBlockWeights._fields_:
+            _chk_dev(blk[name])
+            setattr(p.blk[i], name, L.ptr(blk[name]))
+    p.ws, p.ws_bytes, p.out = L.ptr(ws), ws.numel() * ws.element_size(), L.ptr(out)
+    L.call("ovg_camera_head", p, _stream())
+    return out
+
+
 def unproject(depth, cam):
     """depth f32 [S,H,W], cam f32 [S,16] (cam-to-world R row-major, t, fu, fv, cu, cv) -> world points [S,H,W,3] f32."""
     _chk_dev(depth, cam)

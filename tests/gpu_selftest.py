@@ -686,6 +686,53 @@ def test_attn_lse_merge():
         report("pack_weights_%s" % name, got, exp, 0.0)
 
 
+def test_camera_head(timing=False):
+    """ovg_camera_head (csrc/ovg_camhead.hip) through heads_hip.HipCameraHead against (i) the torch restatement of the
+    entry on the same packed 16-bit weights (tests/head_ops_emul.camera_head: same rounding points, f32 accumulate) and
+    (ii) the f32 PyTorch CameraHead module on CPU (the reference's arithmetic, heads/camera_head.py:84-154).
+    S = 3 (one partial 16-row block), 8, 70 (two 64-token z slices, ragged), 128; also B = 2 and a strided token view."""
+    import head_ops_emul as emul
+    import importlib
+    heads = importlib.import_module("omnivggt_official_amd.heads")
+    heads_hip = importlib.import_module("omnivggt_official_amd.heads_hip")
+    torch.manual_seed(21)
+    head = heads.CameraHead(dim_in=2048).eval()
+    with torch.no_grad():
+        for name, p in head.named_parameters():        # sensitised: LayerScale ~ 0.7, non-zero empty pose, wider matrices
+            if name.endswith("gamma"):
+                p.fill_(0.7)
+            elif name == "empty_pose_tokens":
+                p.normal_(0, 0.5)
+            elif p.dim() > 1:
+                p.mul_(1.5)
+            elif "bias" in name:
+                p.uniform_(-0.1, 0.1)
+    g = torch.Generator().manual_seed(4)
+    head_dev = heads.CameraHead(dim_in=2048).eval()
+    head_dev.load_state_dict(head.state_dict())
+    head_dev = head_dev.to(DEV)
+    hip = heads_hip.HipCameraHead(head_dev)
+    for name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        for B, S in ((1, 3), (1, 8), (2, 8), (1, 70), (1, 128)):
+            toks = rnd(B, S, 3, 2048, g=g) * 1.3                       # tokens_per_view = 3: row stride 3 * 2048
+            with torch.no_grad():
+                ref32 = torch.stack(head([toks]), 0)                   # [4, B, S, 9] f32 module on CPU
+                W = hip._weights(dt, torch.device(DEV))
+                Wc = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in W.items() if k != "blocks"}
+                Wc["blocks"] = [{k: v.cpu() for k, v in blk.items()} for blk in W["blocks"]]
+                twin = torch.stack([emul.camera_head(toks[b, :, 0], Wc, dt) for b in range(B)], 1)
+                got = torch.stack(hip([toks.to(DEV)], dtype=dt), 0)
+            tag = "camera_head_%s_B%d_S%d" % (name, B, S)
+            report(tag + "_vs_twin", got, twin, 1.5e-2 if name == "bf16" else 2e-3)
+            report(tag + "_vs_f32_module", got, ref32, 4e-2 if name == "bf16" else 5e-3)
+    if timing:
+        toks = (rnd(1, 8, 1374, 2048, g=g) * 1.3).to(DEV)
+        for label, fn in (("hip bf16", lambda: hip([toks], dtype=torch.bfloat16)), ("pytorch f32", lambda: head_dev([toks]))):
+            with torch.no_grad():
+                ms = bench(fn, iters=20, warm=5)
+            print("camera head S=8 %-12s %.3f ms per forward (4 refinement rounds)" % (label, ms), flush=True)
+
+
 def bench(fn, iters=10, warm=3):
     for _ in range(warm):
         fn()
@@ -760,7 +807,7 @@ def main():
     tests = {"probe": test_probe, "layernorm": test_layernorm, "linear": lambda: test_linear(args.quick), "qkv": lambda: test_qkv(args.quick),
              "attn": lambda: test_attn(args.quick), "embed": test_embed, "block": lambda: test_block(args.quick),
              "heads": lambda: test_heads(args.quick), "gemm256": lambda: test_gemm256(args.quick), "attn_big": lambda: test_attn_big(args.quick),
-             "lse_merge": test_attn_lse_merge}
+             "lse_merge": test_attn_lse_merge, "camera": lambda: test_camera_head(timing=True)}
     for name, fn in tests.items():
         if args.only and name not in args.only.split(","):
             continue

@@ -58,3 +58,34 @@ def dpt_out(h, w2, b2, activation):
     val, conf = o[..., :-1], o[..., -1]
     val = torch.exp(val) if activation == "exp" else torch.sign(val) * torch.expm1(val.abs())
     return val.contiguous(), (1 + conf.exp()).contiguous()
+
+
+def camera_head(tokens, W, dtype, iters=4, ws=None):
+    """Torch restatement of the ovg_camera_head entry on the PACKED weights (same signature as ops.camera_head):
+    GEMM operands rounded to `dtype` exactly where the kernels store 16-bit tensors, everything else f32."""
+    f = lambda t: t.float()
+    rnd = lambda t: t.to(dtype).float()                     # a 16-bit activation buffer of the kernel
+    lin = lambda x, w, b: rnd(x) @ f(w).t() + f(b)          # x is a 16-bit buffer in the kernel; f32 accumulate
+    ln = lambda x, w, b, eps: F.layer_norm(x, (x.shape[-1],), None if w is None else f(w), None if b is None else f(b), eps)
+    S = tokens.shape[0]
+    nh = W["heads"]
+    tok = ln(tokens.float(), W["token_norm_w"], W["token_norm_b"], 1e-5)
+    pose, outs = None, []
+    for it in range(iters):
+        prev = f(W["empty_pose"]).expand(S, -1) if pose is None else pose
+        e = F.silu(prev @ f(W["embed_w"]).t() + f(W["embed_b"]))
+        shift, scale, gate = lin(e, W["mod_w"], W["mod_b"]).chunk(3, dim=-1)
+        x = gate * (ln(tok, None, None, 1e-6) * (1 + scale) + shift) + tok
+        for blk in W["blocks"]:
+            qkv = rnd(lin(ln(x, blk["n1_w"], blk["n1_b"], 1e-5), blk["qkv_w"], blk["qkv_b"]))
+            q, k, v = qkv.view(S, 3, nh, -1).permute(1, 2, 0, 3)
+            a = torch.softmax(q @ k.transpose(1, 2) * q.shape[-1] ** -0.5, dim=-1) @ v          # [nh, S, hd]
+            a = a.permute(1, 0, 2).reshape(S, -1)
+            x = x + f(blk["ls1"]) * lin(a, blk["proj_w"], blk["proj_b"])
+            hid = F.gelu(lin(ln(x, blk["n2_w"], blk["n2_b"], 1e-5), blk["fc1_w"], blk["fc1_b"]))
+            x = x + f(blk["ls2"]) * lin(hid, blk["fc2_w"], blk["fc2_b"])
+        hb = F.gelu(lin(ln(x, W["trunk_norm_w"], W["trunk_norm_b"], 1e-5), W["pb1_w"], W["pb1_b"]))
+        delta = hb @ f(W["pb2_w"]).t() + f(W["pb2_b"])
+        pose = delta if pose is None else pose + delta
+        outs.append(torch.cat([pose[:, :7], F.relu(pose[:, 7:])], dim=-1))
+    return torch.stack(outs, 0)

@@ -59,7 +59,8 @@ def test_ctypes_struct_layout_matches_c():
              "ovg_conv_params": L.ConvParams, "ovg_upsample_params": L.UpsampleParams, "ovg_dpt_out_params": L.DptOutParams,
              "ovg_unproject_params": L.UnprojectParams, "ovg_heads_to_tokens_params": L.HeadsToTokensParams,
              "ovg_attn_merge_params": L.AttnMergeParams, "ovg_block_workspace": L.BlockWorkspace,
-             "ovg_pack_weights_params": L.PackWeightsParams}
+             "ovg_pack_weights_params": L.PackWeightsParams, "ovg_camera_block_weights": L.CameraBlockWeights,
+             "ovg_camera_head_params": L.CameraHeadParams}
     src = '#include <stdio.h>\n#include "%s"\nint main(){\n' % HEADER
     for name in pairs:
         src += 'printf("%s %%zu\\n", sizeof(%s));\n' % (name, name)
@@ -86,6 +87,15 @@ def test_argument_validation_without_gpu():
     assert lib.ovg_attn_merge(ctypes.byref(L.AttnMergeParams()), None) == -1
     assert lib.ovg_pack_weights(ctypes.byref(L.PackWeightsParams()), None) == -1
     assert not hasattr(lib, "ovg_debug_set")          # ABI 4: no process-global knobs left in the library
+    assert lib.ovg_camera_head(ctypes.byref(L.CameraHeadParams()), None) == -1
+    assert lib.ovg_camera_head(None, None) == -1
+    # the camera head's workspace query is a pure host function: S tokens x (f32 token / residual / pose / 32768 partial
+    # columns + 16-bit LN, embed, qkv, attention and hidden buffers), every piece rounded up to 256 bytes
+    r = lambda n: (n + 255) // 256 * 256
+    for S in (1, 8, 128):
+        want = 2 * r(S * 2048 * 4) + r(S * 9 * 4) + r(S * 32768 * 4) + 3 * r(S * 2048 * 2) + r(S * 6144 * 2) + r(S * 8192 * 2)
+        assert lib.ovg_camera_head_workspace_bytes(S, L.OVG_BF16) == want
+    assert lib.ovg_camera_head_workspace_bytes(8, L.OVG_F32) == -1 and lib.ovg_camera_head_workspace_bytes(0, L.OVG_BF16) == -1
 
 
 def test_block_workspace_query_matches_the_python_allocation():

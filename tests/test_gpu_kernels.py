@@ -61,6 +61,12 @@ def test_dpt_head_kernels_and_whole_head():
     _assert_clean()
 
 
+def test_camera_head_entry_vs_twin_and_f32_module():
+    """SURVEY 8(f) N1 remainder: the whole iterative camera head on ovg_camera_head (split-K weight-stream GEMMs)."""
+    st.test_camera_head()
+    _assert_clean()
+
+
 def test_gemm256_kernels_every_epilogue_ragged_m():
     """The 256 x 256 ping-pong GEMMs the 64-view bench runs (qkv256_kernel, linear256_kernel<GELU|RES|STORE|PATCH>)."""
     st.test_gemm256(False)

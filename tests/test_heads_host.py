@@ -61,3 +61,41 @@ def test_uv_tables_are_the_separable_form_of_the_reference_embedding():
         half = ch // 2
         assert torch.equal(emb[:half], px.t()[:, None, :].expand(half, ph, pw))
         assert torch.equal(emb[half:], py.t()[:, :, None].expand(half, ph, pw))
+
+
+def _rand_camera_head(seed):
+    torch.manual_seed(seed)
+    h = heads.CameraHead(dim_in=2048).eval()
+    with torch.no_grad():
+        for name, p in h.named_parameters():          # default init: LayerScale 0.01, empty pose 0 -> the trunk would be nearly silent
+            if name.endswith("gamma"):
+                p.fill_(0.7)
+            elif name == "empty_pose_tokens":
+                p.normal_(0, 0.5)
+            elif p.dim() > 1:
+                p.mul_(1.5)
+            elif "bias" in name:
+                p.uniform_(-0.1, 0.1)
+            elif "norm" in name and name.endswith("weight"):
+                p.uniform_(0.8, 1.2)
+    return h
+
+
+def test_hip_camera_head_host_logic_matches_pytorch_head(monkeypatch):
+    """heads_hip.HipCameraHead (weight packing, token view, batch loop, output list) on the torch restatement of the
+    ovg_camera_head entry == the PyTorch CameraHead (itself oracle-checked, test_cpu_contract) in f32."""
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    head = _rand_camera_head(3)
+    g = torch.Generator().manual_seed(9)
+    B, S, P = 2, 5, 7
+    toks = [torch.randn(B, S, P, 2048, generator=g) * 1.3]
+    with torch.no_grad():
+        ref = head(toks)
+        monkeypatch.setattr(heads_hip.ops, "camera_head", emul.camera_head)
+        monkeypatch.setattr(heads_hip.ops, "camera_head_workspace_bytes", lambda S, dtype: 16)
+        got = heads_hip.HipCameraHead(head)(toks, dtype=torch.float32)
+    assert len(got) == len(ref) == 4
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape == (B, S, 9)
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-5
+    assert float(ref[-1].abs().max()) > 1e-2 and float((ref[-1] - ref[0]).abs().max()) > 1e-3      # the refinement rounds do something
