@@ -45,9 +45,19 @@ from omnivggt_official_amd.model import OmniVGGT  # noqa: E402
 P_TOK, C = 1374, 1024
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}     # MI355X_MICROARCH.md, dense MFMA
 DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
-KERNEL_NAME = {"bf16": "attn16_kernel<bf16,QB=4,WAVES=4,MODE=0> (speculative anchored softmax + verified fallback)",
-               "f16": "attn16_kernel<f16,QB=4,WAVES=4,MODE=1> (lazy-rescale online softmax)",
+KERNEL_NAME = {"bf16": "attn16_kernel<bf16,QB=4,WAVES=%d,MODE=0> (speculative anchored softmax + verified fallback; %d-row q tiles)",
+               "f16": "attn16_kernel<f16,QB=4,WAVES=%d,MODE=1> (lazy-rescale online softmax; %d-row q tiles)",
                "f32": "attn_kernel<float,QB=1> (exact-f32 MFMA 16x16x4, classic online softmax)"}
+
+
+def kernel_name(dtype_name, n_q, n_k):
+    """Name of the global-attention kernel the library's launch plan picks for this shape (ovg_attn_plan)."""
+    if dtype_name == "f32":
+        return KERNEL_NAME["f32"]
+    from omnivggt_official_amd import ops
+    plan = ops.attn_plan(16, n_q, [n_k], DT[dtype_name])
+    name = KERNEL_NAME[dtype_name] % (plan["q_tile"] // 64, plan["q_tile"])
+    return name + (", split-KV x%d" % plan["splits"] if plan["splits"] > 1 else "")
 PARITY_LAYERS = (0, 4, 11, 17, 23)
 
 
@@ -195,7 +205,7 @@ def main():
                        "parallelism": "view-shard x%d%s" % (world, form)},
             "algorithmic_tflop_per_step": round(f_total / 1e12, 2),
             "tflops_per_gpu": round(f_total / 1e12 / (dt / steps) / world, 1),
-            "roofline": {"bound": "mfma", "kernel": KERNEL_NAME[args.dtype] + " (global cross-view attention, D=64)",
+            "roofline": {"bound": "mfma", "kernel": kernel_name(args.dtype, n_local * P_TOK, S * P_TOK) + " (global cross-view attention, D=64)",
                          "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                          "flop_per_launch": attn_flop / max(launches, 1), "avg_launch_ms": round(attn_ms / max(launches, 1), 4),
                          "launches_timed": launches},
