@@ -63,13 +63,13 @@ def main():
         if "SQ_WAIT_INST_ANY" in c and "SQ_WAVE_CYCLES" in c:
             d.append("issue-stall (WAIT_INST_ANY) = %.1f %%, parked (WAIT_ANY) = %.1f %% of wave cycles" %
                      (100 * c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 100 * c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"]))
-        if "SQ_VALU_MFMA_COEXEC_CYCLES" in c and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+        if "SQ_VALU_MFMA_COEXEC_CYCLES" in c and c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
             d.append("MFMA/VALU co-execution = %.1f %% of MFMA-busy cycles" % (100 * c["SQ_VALU_MFMA_COEXEC_CYCLES"] / c["SQ_VALU_MFMA_BUSY_CYCLES"]))
         if "SQ_INSTS_VALU" in c and "SQ_INSTS_MFMA" in c and c["SQ_INSTS_MFMA"]:
             d.append("non-MFMA VALU per MFMA = %.2f" % ((c["SQ_INSTS_VALU"] - c["SQ_INSTS_MFMA"]) / c["SQ_INSTS_MFMA"]))
         if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE"):
             d.append("LDS bank-conflict cycles = %.1f %% of LDS-active" % (100 * c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]))
-        if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+        if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
             d.append("L2 hit rate = %.1f %%" % (100 * c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])))
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             d.append("fabric bytes per launch = FETCH_SIZE[KiB] x 1024 x 2 + WRITE_SIZE[KiB] x 1024 = %.4g" % (c["FETCH_SIZE"] * 2048 + c["WRITE_SIZE"] * 1024))
