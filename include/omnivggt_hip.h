@@ -38,7 +38,7 @@ extern "C" {
  * 4: per-call GEMM tile selector (`tile`) replacing the process-global debug setter of ABI 3, optional
  *    log-sum-exp output of ovg_flash_attn + ovg_attn_merge (two-launch local-first sharded attention),
  *    ovg_block_workspace_bytes, ovg_pack_weights, split-KV attention (kv_splits / ws_part / ws_lse, ovg_attn_plan) */
-#define OVG_ABI_VERSION 5
+#define OVG_ABI_VERSION 6
 
 enum { OVG_BF16 = 0, OVG_F16 = 1, OVG_F32 = 2 };
 
@@ -119,6 +119,11 @@ int ovg_linear(const ovg_linear_params*, void* stream);
  * (1 + (t-5)/grid_w, 1 + (t-5)%grid_w)   (omnivggt_aggregator.py:215-224).
  * rope_cos/rope_sin: f32 [max_pos,16] (rope.py:86-117, 16 unique freqs), max_pos <= 128 (staged in LDS).
  * Padding rows/cols of q,k,vt are never written (caller zero-fills once).
+ * Column order of a vt row (ABI 6). OVG_F32: natural (column n = key n). OVG_BF16 / OVG_F16: inside every block of 32 keys
+ * column 8 g + 4 h + i holds key 16 h + 4 g + i (g < 4, h < 2, i < 4) -- each 16-byte chunk is then exactly the B^T fragment
+ * of one lane group of the PV MFMA, so the attention kernels move K / V^T tiles global -> LDS by LDS-DMA (no register pass)
+ * and read a fragment with one ds_read_b128. ovg_qkv writes this order and ovg_flash_attn expects it; the permutation is
+ * local to 32-key blocks, so slicing / exchanging vt buffers at 64-key granularity (segments, ranks, heads) is unaffected.
  * ------------------------------------------------------------------ */
 typedef struct {
   const void* x; int64_t ldx;       /* [M,1024] dtype */
@@ -143,7 +148,7 @@ int ovg_qkv(const ovg_qkv_params*, void* stream);
  * exp2.  K/V^T arrive as `nseg` segments (1 on a single GPU; one per rank
  * after the view-sharded all-gather) -- softmax runs across all of them.
  *   q   [BH, nq_pad, 64]
- *   seg[i].k [BH, nk_pad_i, 64], seg[i].vt [BH, 64, nk_pad_i], nk_i valid keys
+ *   seg[i].k [BH, nk_pad_i, 64], seg[i].vt [BH, 64, nk_pad_i] (16-bit: columns in the ovg_qkv order above), nk_i valid keys
  *   out [B*nq, H*64] token-major (row = (bh/H)*nq + n, col = (bh%H)*64 + d), ld = ldo
  * ------------------------------------------------------------------ */
 typedef struct { const void* k; const void* vt; int64_t nk; int64_t nk_pad; } ovg_kv_segment;

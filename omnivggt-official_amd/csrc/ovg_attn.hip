@@ -11,7 +11,7 @@
 // running max/sum/alpha are lane-local, and P feeds the PV MFMA with NO cross-lane
 // movement: the k-slot -> key assignment of the P fragment is simply mirrored by the
 // V^T fragment gather (two 8-byte LDS reads per fragment for 16-bit types).
-// V arrives pre-transposed (V^T [BH,64,nk_pad], written by the QKV epilogue), K/V^T tiles
+// V arrives pre-transposed (V^T [BH,64,nk_pad], written by the QKV epilogue; 16-bit rows in the vt_pos16 key order), K/V^T tiles
 // are register-staged into double-buffered LDS (issue-early / write-late), the K tile is
 // XOR-swizzled and the V^T tile row-padded so every fragment read is conflict free.
 // q is pre-scaled by softmax_scale*log2(e): probabilities are exp2(s - m).
@@ -30,9 +30,10 @@ template <typename T> struct VFrag {
   static constexpr int kSteps = 2;
   static constexpr int kRow = 136;   // V^T LDS row stride (128 B + 8 B pad): b64 reads conflict free
   static OVG_DEV u32x4 load(const unsigned char* vl, int d, int step, int g) {
-    const unsigned char* p = vl + d * kRow + (32 * step + 4 * g) * 2;
+    // global V^T rows are in the vt_pos16 order (ovg_common.h): chunk g of block `step` IS the fragment (keys 4g.., 16+4g..)
+    const unsigned char* p = vl + d * kRow + (32 * step + 8 * g) * 2;
     const u32x2 lo = *reinterpret_cast<const u32x2*>(p);
-    const u32x2 hi = *reinterpret_cast<const u32x2*>(p + 32);
+    const u32x2 hi = *reinterpret_cast<const u32x2*>(p + 8);
     return u32x4{lo[0], lo[1], hi[0], hi[1]};
   }
   static OVG_DEV u32x4 pfrag(const f32x4 (&s)[4], int step) {
@@ -296,15 +297,15 @@ Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
   int v = p.variant;
   const int cus = cu_count_attn();
   const int64_t units512 = p.BH * ((p.nq + 511) / 512);
-  if (v == 0) v = bf16 ? (units512 >= 8 * (int64_t)cus ? 33 : 21) : (p.nq >= 4096 ? 6 : 8);
+  if (v == 0) v = bf16 ? (units512 >= 8 * (int64_t)cus ? 51 : 50) : (p.nq >= 4096 ? 52 : 55);
   pl.variant = v;
-  pl.bq = (v == 33) ? 512 : ((v == 8 || v == 25 || v == 19) ? 128 : 256);
+  pl.bq = (v == 33 || v == 51) ? 512 : ((v == 8 || v == 25 || v == 19 || v == 54 || v == 55) ? 128 : 256);
   pl.total_tiles = total_key_tiles(p);
-  const int slots = (v == 33) ? cus : 2 * cus;
+  const int slots = (v == 33 || v == 51) ? cus : 2 * cus;
   const int64_t units = p.BH * ((p.nq + pl.bq - 1) / pl.bq);
   int splits = 1;
   if (p.kv_splits > 1) splits = p.kv_splits;
-  else if (p.kv_splits == 0 && have_ws && (v == 21 || v == 6 || v == 33)) {
+  else if (p.kv_splits == 0 && have_ws && (v == 21 || v == 6 || v == 33 || v == 50 || v == 51 || v == 52)) {
     // Measured model (profiles/r02_attention_splitkv_ab.txt): a launch of R = units / slots rounds runs at eff(R) = 1 - 0.155 / R^1.2
     // of the many-round rate (0.89 at R = 1.34, 0.95 at 2.7, 0.98 at 5.4: the tail rounds run with fewer co-resident
     // workgroups and are faster than a full one, so the loss is smaller than ceil(R) / R); a split costs ~1.5 key tiles per
@@ -332,12 +333,12 @@ Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
   return pl;
 }
 
-template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false>
+template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false, bool DMA = false>
 int launch_attn16(const ovg_attn_params& p, const Plan16& pl, hipStream_t st) {
   constexpr int BQ = 16 * QB * WAVES;
   const int nqt = (int)((p.nq + BQ - 1) / BQ);
   const dim3 grid((unsigned)(p.BH * nqt * pl.splits)), block(64 * WAVES);
-  OVG_LAUNCH((attn16_kernel<T, QB, WAVES, MODE, OCC, VSUM>), grid, block, 0, st, p, nqt, pl.total_tiles, pl.splits, pl.per_split);
+  OVG_LAUNCH((attn16_kernel<T, QB, WAVES, MODE, OCC, VSUM, DMA>), grid, block, 0, st, p, nqt, pl.total_tiles, pl.splits, pl.per_split);
   OVG_CHECK_LAUNCH();
   if (pl.splits > 1) {
     const int64_t total = p.BH * p.nq * 8;
@@ -349,13 +350,17 @@ int launch_attn16(const ovg_attn_params& p, const Plan16& pl, hipStream_t st) {
 }
 
 // variant (benchmark / test knob; numbers kept from the A/B logs under profiles/):
-//   0 = default: bf16 -> speculative kernel, q tile and split-KV factor from plan16; f16 -> lazy-rescale kernel
+//   0 = default: bf16 -> speculative kernel, q tile and split-KV factor from plan16; f16 -> lazy-rescale kernel; both LDS-DMA staged
 //   1 / 2   baseline kernel, QB = 1 / 2 (never split)
 //   6 / 8   attn16 lazy-rescale only (MODE 1), QB = 4 / 2
 //   21 / 25 attn16 speculative + verified fallback (MODE 0), QB = 4 / 2
 //   18 / 19 attn16 with the fallback forced (MODE 2, tests), QB = 4 / 2
 //   31 / 32 r02 experiments: row sums on the VALU / 8 waves x 32 rows at 4 waves per SIMD (both slower, kept for the A/B tool)
-//   33      8 waves x 64 rows = 512-row q tiles, 1 workgroup per CU (chosen automatically for launches of >= 8 rounds)
+//   33      8 waves x 64 rows = 512-row q tiles, 1 workgroup per CU, register-staged (the r02 default for launches of >= 8 rounds)
+//   50 / 51 / 54   LDS-DMA staging (3-slot ring, two tiles ahead): speculative kernel with 256- / 512- / 128-row q tiles -- the bf16 default
+//                  (51 for launches of >= 8 rounds of 512-row tiles, else 50)
+//   52 / 55        LDS-DMA staging, lazy-rescale kernel, 256- / 128-row q tiles -- the f16 default (52 for nq >= 4096, else 55)
+//   53             LDS-DMA staging with the fallback forced (tests)
 template <typename T>
 int dispatch16(const ovg_attn_params& p, hipStream_t st) {
   constexpr bool kBf16 = std::is_same<T, bf16_t>::value;
@@ -373,6 +378,12 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
     case 31: return launch_attn16<T, 4, 4, 0, 2, true>(p, pl, st);
     case 32: return launch_attn16<T, 2, 8, 0, 4>(p, pl, st);
     case 33: return launch_attn16<T, 4, 8, 0, 2>(p, pl, st);
+    case 50: return launch_attn16<T, 4, 4, 0, 2, false, true>(p, pl, st);
+    case 51: return launch_attn16<T, 4, 8, 0, 2, false, true>(p, pl, st);
+    case 52: return launch_attn16<T, 4, 4, 1, 2, false, true>(p, pl, st);
+    case 53: return launch_attn16<T, 4, 4, 2, 2, false, true>(p, pl, st);
+    case 54: return launch_attn16<T, 2, 4, 0, 2, false, true>(p, pl, st);
+    case 55: return launch_attn16<T, 2, 4, 1, 2, false, true>(p, pl, st);
     default: return OVG_E_ARG;
   }
 }

@@ -100,7 +100,18 @@ OVG_DEV u32x4 pack2(const f32x4 a, const f32x4 b) {
 // One pass over all key tiles of all segments for the wave's QB x 16 query rows; leaves the un-normalised
 // O^T in o, the row sums in lacc (every register of lacc[qb] holds the full sum of row q0 + 16 qb + lane&15) and the
 // negated reference maximum in negm (P = exp2(s + negm)): log2 sum_k exp2(s) = log2(lacc) - negm.
-template <typename T, int QB, int WAVES, int SM, bool VSUM = false>   // VSUM: row sums on the VALU (experiment, variant 31) instead of the ones-MFMA
+// LDS-DMA of one 16-byte granule per lane: lane l of the wave lands at lds_dst + 16 l (lds_dst wave-uniform, in M0).
+// Inline asm on purpose: hipcc treats the builtin form as a FLAT access that may touch LDS ("pending flat"), after which
+// EVERY s_waitcnt it generates in the loop becomes vmcnt(0) / lgkmcnt(0) -- the prefetch is drained where it was issued and
+// the ds_read pipelining of the tile body is lost. Opaque to the compiler, the transfers are covered by the explicit counted
+// s_waitcnt vmcnt in run_tiles.
+OVG_DEV void lds_dma16(const void* gsrc, uint32_t lds_dst) {
+  // M0 is written without being declared (it is a reserved register: hipcc rejects it as a clobber); hipcc itself never keeps a
+  // value live in M0 on gfx9+ -- it materialises M0 immediately in front of each of its own uses (LDS-DMA builtin, s_sendmsg).
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_dst), "v"(gsrc) : "memory");
+}
+
+template <typename T, int QB, int WAVES, int SM, bool VSUM = false, bool DMA = false>   // VSUM: row sums on the VALU (experiment, variant 31) instead of the ones-MFMA; DMA: K / V^T tiles by LDS-DMA into a 3-slot ring, two tiles ahead
 OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int bh, const int q0, const int t_begin, const int total_tiles,
                        f32x4 (&o)[QB][4], f32x4 (&lacc)[QB], f32x4 (&negm)[QB]) {   // key tiles [t_begin, t_begin + total_tiles) of the flattened segment list
   constexpr int NT = 64 * WAVES;
@@ -130,9 +141,16 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
   }
   const u32x4 ones = OnesFrag<T>::get();
 
-  // ---- staging: per-thread chunk coordinates; tile pointers advance incrementally -----------------
-  u32x4 rk[CPT], rv[CPT];
-  int k_goff[CPT], v_row[CPT], v_coff[CPT], k_loff[CPT], v_loff0[CPT], v_loff1[CPT];
+  // ---- staging ------------------------------------------------------------------------------------------------------------
+  // Register path (DMA = false): global loads of tile j + 1 are issued before the MFMAs of tile j and written to the other LDS
+  // buffer after them (two buffers of K tile + V^T tile).  DMA path: both tiles go global -> LDS by LDS-DMA into a ring of three
+  // slots, TWO tiles ahead, no staging registers and no ds_write; every iteration issues exactly NDMA transfers per wave, so one
+  // counted s_waitcnt vmcnt(NDMA) before the barrier means "everything but the newest tile has landed".
+  //   lane l of a transfer -> LDS row l / 8, chunk position l % 8 of that row <- source chunk (l % 8) ^ swizzle(row), i.e. the LDS image
+  //   is the XOR-swizzled tile the fragment reads expect (K rows = keys, V^T rows = features with the vt_pos16 key order).
+  constexpr int SLOT_B = KT_B + VT_B, NDMA = 2 * (8 / WAVES);
+  u32x4 rk[DMA ? 1 : CPT], rv[DMA ? 1 : CPT];
+  int k_goff[CPT], v_row[CPT], v_coff[CPT], k_loff[CPT], v_loff[CPT];
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
     const int c = tid + NT * i;
@@ -140,9 +158,7 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
     k_goff[i] = c * 16;
     k_loff[i] = swz_off<128>(row, ch);
     v_row[i] = row; v_coff[i] = ch * 16;
-    const int u = ch >> 2, c4 = ch & 3;            // key permutation inside each 32-key block
-    v_loff0[i] = swz_off<128>(row, 4 * u + 2 * (c4 & 1) + 0) + 8 * (c4 >> 1);
-    v_loff1[i] = swz_off<128>(row, 4 * u + 2 * (c4 & 1) + 1) + 8 * (c4 >> 1);
+    v_loff[i] = swz_off<128>(row, ch);             // global V^T rows already hold the fragment order (vt_pos16)
   }
   int fseg = 0, ftile = t_begin;                   // split-KV: this pass starts t_begin tiles into the segment list
   int f_ntiles = (int)((p.seg[0].nk + BC - 1) / BC);
@@ -152,12 +168,7 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
   const unsigned char* vptr = static_cast<const unsigned char*>(p.seg[fseg].vt) + ((int64_t)kvh * OVG_D * p.seg[fseg].nk_pad + (int64_t)ftile * BC) * 2;
   int64_t vstride = p.seg[fseg].nk_pad * 2;       // bytes between V^T rows (d)
   const int seg0 = fseg, tile0 = ftile;
-  auto fetch = [&]() {
-#pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      rk[i] = *reinterpret_cast<const u32x4*>(kptr + k_goff[i]);
-      rv[i] = *reinterpret_cast<const u32x4*>(vptr + v_row[i] * vstride + v_coff[i]);
-    }
+  auto next_tile = [&]() {                          // advance the fetch cursor (kptr / vptr / vstride) by one tile, across segments
     kptr += KT_B;
     vptr += BC * 2;
     if (++ftile == f_ntiles) {
@@ -171,15 +182,41 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
       }
     }
   };
+  auto fetch = [&]() {
+#pragma unroll
+    for (int i = 0; i < (DMA ? 1 : CPT); ++i) {
+      rk[i] = *reinterpret_cast<const u32x4*>(kptr + k_goff[i]);
+      rv[i] = *reinterpret_cast<const u32x4*>(vptr + v_row[i] * vstride + v_coff[i]);
+    }
+    next_tile();
+  };
   auto stash = [&](int buf) {
     unsigned char* kl = lds + buf * (KT_B + VT_B);
     unsigned char* vl = kl + KT_B;
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) {
+    for (int i = 0; i < (DMA ? 1 : CPT); ++i) {
       *reinterpret_cast<u32x4*>(kl + k_loff[i]) = rk[i];
-      *reinterpret_cast<u32x2*>(vl + v_loff0[i]) = u32x2{rv[i][0], rv[i][1]};
-      *reinterpret_cast<u32x2*>(vl + v_loff1[i]) = u32x2{rv[i][2], rv[i][3]};
+      *reinterpret_cast<u32x4*>(vl + v_loff[i]) = rv[i];
     }
+  };
+  // DMA path: per-lane source offsets of the wave's 8 / WAVES transfers per tile and the wave-uniform LDS destinations
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+  int d_row[8 / WAVES], d_ch16[8 / WAVES];
+#pragma unroll
+  for (int i = 0; i < 8 / WAVES; ++i) {
+    d_row[i] = (64 / WAVES) * wave_u + 8 * i + (lane >> 3);
+    d_ch16[i] = ((lane & 7) ^ ((d_row[i] >> 1) & 7)) << 4;
+  }
+  int issued = 0;                                  // tiles handed to the DMA engine so far (the cursor stops on the last tile:
+                                                   // the tail iterations re-load it into slots nobody reads, keeping NDMA per iteration)
+  auto dma_issue = [&](int slot) {
+    const uint32_t dst = lds_base + slot * SLOT_B + (64 / WAVES) * wave_u * RB;
+#pragma unroll
+    for (int i = 0; i < 8 / WAVES; ++i) lds_dma16(kptr + d_row[i] * RB + d_ch16[i], dst + i * 8 * RB);
+#pragma unroll
+    for (int i = 0; i < 8 / WAVES; ++i) lds_dma16(vptr + d_row[i] * vstride + d_ch16[i], dst + KT_B + i * 8 * RB);
+    if (++issued < total_tiles) next_tile();
   };
 
   int cseg = seg0, ctile = tile0;
@@ -189,9 +226,16 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
   const int frag_row = lr * 128;
   const int coff0 = ((0 + g) ^ sx) << 4, coff1 = ((4 + g) ^ sx) << 4;
 
-  fetch();
-  stash(0);
-  __syncthreads();
+  if constexpr (DMA) {
+    dma_issue(0);
+    dma_issue(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");     // tile 0 has landed (this wave's share), tile 1 may be in flight
+    __builtin_amdgcn_s_barrier();
+  } else {
+    fetch();
+    stash(0);
+    __syncthreads();
+  }
 
   // S'^T blocks s[kt][qb] (keys 16 kt .. 16 kt + 15) of the tile in LDS at kl, dead keys masked to -inf
   auto qk_tile = [&](const unsigned char* kl, f32x4 (&s)[4][QB], bool tail, int kv0) {
@@ -261,10 +305,14 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
     }
   }
 
-  int buf = 0;
+  int buf = 0;                                     // register path: LDS buffer of tile j; DMA path: ring slot of tile j
   for (int j = 0; j < total_tiles; ++j) {
     const bool more = (j + 1) < total_tiles;
-    if (more) fetch();
+    if constexpr (DMA) {
+      dma_issue(buf == 0 ? 2 : buf - 1);             // tile j + 2 -> slot (j + 2) % 3, last read as tile j - 1 (before the previous barrier)
+    } else {
+      if (more) fetch();
+    }
     const unsigned char* kl = lds + buf * (KT_B + VT_B);
     const unsigned char* vl = kl + KT_B;
     const int kv0 = ctile * BC;
@@ -302,10 +350,19 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
       ctile = 0; ++cseg;
       if (cseg < p.nseg) { c_nk = (int)p.seg[cseg].nk; c_ntiles = (c_nk + BC - 1) / BC; }
     }
-    if (more) stash(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
+    if constexpr (DMA) {
+      // this wave's share of tile j + 1 was issued one iteration ago: all but the NDMA transfers of this iteration have landed.
+      // No __syncthreads (its fence drains vmcnt), no LDS writes by the waves: a bare barrier publishes tile j + 1 and retires tile j.
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+      __builtin_amdgcn_s_barrier();
+      buf = buf == 2 ? 0 : buf + 1;
+    } else {
+      if (more) stash(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
   }
+  if constexpr (DMA) __syncthreads();              // drain the tail transfers before the ring is reused (fallback pass) or the workgroup ends
   if constexpr (VSUM) {
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -350,11 +407,11 @@ OVG_DEV void write_out(const ovg_attn_params& p, const f32x4 (&o)[QB][4], const 
 }  // namespace attn16
 
 // MODE: 0 = speculative anchored softmax + verified fallback, 1 = lazy-rescale only, 2 = forced fallback (tests)
-template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false>   // OCC: minimum waves per SIMD the register allocation must allow
+template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false, bool DMA = false>   // OCC: minimum waves per SIMD the register allocation must allow
 __global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params p, int nqt, int total_tiles, int splits, int per_split) {
   static_assert(sizeof(T) == 2, "16-bit types only");
   constexpr int RB = 128, KT_B = BC * RB, VT_B = OVG_D * RB, BQ = 16 * QB * WAVES;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (KT_B + VT_B)];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(DMA ? 3 : 2) * (KT_B + VT_B)];
 
   const int tid = threadIdx.x, wave = tid >> 6;
   // logical id -> (batch entry, key split, q tile), q tile fastest: the workgroups that run side by side on an XCD share
@@ -368,9 +425,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params
 
   f32x4 o[QB][4], lacc[QB], negm[QB];
   if constexpr (MODE == 1) {
-    attn16::run_tiles<T, QB, WAVES, 0, VSUM>(p, lds, bh, q0, t0, nt, o, lacc, negm);
+    attn16::run_tiles<T, QB, WAVES, 0, VSUM, DMA>(p, lds, bh, q0, t0, nt, o, lacc, negm);
   } else {
-    attn16::run_tiles<T, QB, WAVES, 2, VSUM>(p, lds, bh, q0, t0, nt, o, lacc, negm);
+    attn16::run_tiles<T, QB, WAVES, 2, VSUM, DMA>(p, lds, bh, q0, t0, nt, o, lacc, negm);
     bool bad = MODE == 2;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -380,7 +437,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params
 #pragma unroll
         for (int r = 0; r < 4; ++r) bad = bad || attn16::nonfinite(o[qb][dt][r]);
     }
-    if (__syncthreads_or(bad ? 1 : 0)) attn16::run_tiles<T, QB, WAVES, 0, VSUM>(p, lds, bh, q0, t0, nt, o, lacc, negm);
+    if (__syncthreads_or(bad ? 1 : 0)) attn16::run_tiles<T, QB, WAVES, 0, VSUM, DMA>(p, lds, bh, q0, t0, nt, o, lacc, negm);
   }
 
   attn16::write_out<T, QB>(p, o, lacc, negm, bh, q0, sp, splits);

@@ -82,6 +82,16 @@ template <int RB> OVG_DEV int swz_off(int row, int chunk) {
   else return row * 256 + ((chunk ^ (row & 15)) << 4);
 }
 
+// Column of key n inside a 16-bit V^T row (ovg_qkv writes it, the 16-bit attention kernels read it): inside every block of 32
+// keys the order is pos = 8 g + 4 h + i for key = 16 h + 4 g + i (g < 4, h < 2, i < 4), i.e. the 16-byte chunk g of a block
+// holds keys {4g .. 4g+3, 16+4g .. 16+4g+3} -- exactly the PV MFMA B^T fragment of lane group g, so a K / V^T tile goes from
+// global memory to its LDS image by LDS-DMA (16-byte granules, no register pass) and a fragment is one ds_read_b128.
+// f32 V^T rows stay in natural order.
+OVG_DEV int vt_pos16(int n) {
+  const int k = n & 31;
+  return (n & ~31) | ((k & 12) << 1) | ((k & 16) >> 2) | (k & 3);
+}
+
 // x / d and x % d for 0 <= x < 2^24, 1 <= d: one v_rcp_f32 per divisor (hoisted by the caller), then ~8 VALU per
 // division instead of the ~30 of the generic 32-bit sequence hipcc expands (the epilogues divide token indices by the
 // sequence length / tokens per view / patch-grid width once per 16-row block: r02 profile of the QKV kernel showed

@@ -401,17 +401,29 @@ OVG_DEV void v_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], cons
     const int mc = m < M ? m : M - 1;
     int bidx, n;
     div_seq.divmod(mc, bidx, n);
-    // all four tokens valid and in the same sequence, and the vector store naturally aligned to its element group: the 8-byte
-    // store of the 16-bit modes needs n even (true at 518^2: m % 4 == 0 and 1374 is even; odd token counts take the scalar
-    // path on every other view), the 16-byte store of the f32 mode needs n % 4 == 0
-    const bool whole = (m + 3 < M) && (n + 3 < seq) && ((n & (sizeof(T) == 2 ? 1 : 3)) == 0);
-    T* row0 = vt + (((int64_t)bidx * OVG_H + h) * OVG_D + lr) * p.nk_pad + n;
+    // all four tokens valid and in the same sequence, and the vector store naturally aligned to its element group
+    // 16-bit V^T rows hold their keys in the vt_pos16 order (ovg_common.h): the four tokens n .. n + 3 are one 8-byte group when
+    // n % 4 == 0 and two 4-byte halves of neighbouring groups when n % 4 == 2 (odd views at 518^2: 1374 = 2 mod 4)
+    const bool inside = (m + 3 < M) && (n + 3 < seq);
+    const bool whole = inside && ((n & 3) == 0);
+    const bool halves = sizeof(T) == 2 && inside && ((n & 3) == 2);
+    T* rowb = vt + (((int64_t)bidx * OVG_H + h) * OVG_D + lr) * p.nk_pad;
+    const int c0 = sizeof(T) == 2 ? vt_pos16(n) : n, c2 = sizeof(T) == 2 ? vt_pos16(n + 2) : n + 2;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const f32x4 v = acc[nt][mt] + bias[nt];
-      T* dst = row0 + (int64_t)nt * 16 * p.nk_pad;
+      T* dst = rowb + (int64_t)nt * 16 * p.nk_pad;
       if (whole) {
-        store4<T>(dst, v[0], v[1], v[2], v[3]);
+        store4<T>(dst + c0, v[0], v[1], v[2], v[3]);
+      } else if (halves) {
+        if constexpr (sizeof(T) == 2) {
+          T pr[4] = {TT<T>::from_f32(v[0]), TT<T>::from_f32(v[1]), TT<T>::from_f32(v[2]), TT<T>::from_f32(v[3])};
+          uint32_t w0, w1;
+          __builtin_memcpy(&w0, pr, 4);
+          __builtin_memcpy(&w1, pr + 2, 4);
+          *reinterpret_cast<uint32_t*>(dst + c0) = w0;
+          *reinterpret_cast<uint32_t*>(dst + c2) = w1;
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -419,7 +431,7 @@ OVG_DEV void v_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], cons
           if (mr < M) {
             int br, nr;
             div_seq.divmod(mr, br, nr);
-            vt[(((int64_t)br * OVG_H + h) * OVG_D + nt * 16 + lr) * p.nk_pad + nr] = TT<T>::from_f32(v[r]);
+            vt[(((int64_t)br * OVG_H + h) * OVG_D + nt * 16 + lr) * p.nk_pad + (sizeof(T) == 2 ? vt_pos16(nr) : nr)] = TT<T>::from_f32(v[r]);
           }
         }
       }

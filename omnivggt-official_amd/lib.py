@@ -14,7 +14,7 @@ OVG_BF16, OVG_F16, OVG_F32 = 0, 1, 2
 EPI_STORE, EPI_GELU, EPI_RES, EPI_PATCH = 0, 1, 2, 3
 OVG_MAX_SEG = 8
 KV_TILE = 64
-ABI_VERSION = 5
+ABI_VERSION = 6
 TILE_AUTO, TILE_128, TILE_256 = 0, 1, 2
 
 ERRORS = {0: "OVG_OK", -1: "OVG_E_ARG", -2: "OVG_E_DTYPE", -3: "OVG_E_LAUNCH", -4: "OVG_E_UNSUPPORTED"}

@@ -58,8 +58,36 @@ def linear(x, w, bias, dtype, epilogue=L.EPI_STORE, out=None, out_f32=False, res
     return out
 
 
+def vt_index(n_pad, dtype, device="cpu"):
+    """Column permutation of a V^T row: idx[pos] = key stored at column pos. 16-bit dtypes: inside every block of 32 keys
+    pos = 8 g + 4 h + i holds key 16 h + 4 g + i (the PV fragment order, csrc/ovg_common.h vt_pos16); f32: identity."""
+    pos = torch.arange(n_pad, device=device)
+    if dtype == torch.float32:
+        return pos
+    k = pos & 31
+    return (pos & ~31) | (((k >> 2) & 1) << 4) | (((k >> 3) & 3) << 2) | (k & 3)
+
+
+def set_vt(vt, v_nat):
+    """Fill a V^T buffer [BH,64,nk_pad] from natural-order values v_nat [BH,64,n] (n <= nk_pad; the rest is zeroed)."""
+    BH, d, n_pad = vt.shape
+    full = torch.zeros(BH, d, n_pad, device=vt.device, dtype=vt.dtype)
+    full[:, :, : v_nat.shape[2]] = v_nat.to(device=vt.device, dtype=vt.dtype)
+    vt.copy_(full[:, :, vt_index(n_pad, vt.dtype, vt.device)])
+    return vt
+
+
+def get_vt(vt):
+    """Natural-order view (a copy) of a V^T buffer [BH,64,nk_pad] written by ovg_qkv."""
+    idx = vt_index(vt.shape[2], vt.dtype, vt.device)
+    out = torch.empty_like(vt)
+    out[:, :, idx] = vt
+    return out
+
+
 def alloc_qkv(BH, nq, nk, dtype, device):
-    """Zero-filled head-major buffers q [BH,nq_pad,64], k [BH,nk_pad,64], vt [BH,64,nk_pad]."""
+    """Zero-filled head-major buffers q [BH,nq_pad,64], k [BH,nk_pad,64], vt [BH,64,nk_pad] (16-bit vt rows hold their keys in
+    the vt_index order: fill / read them with set_vt / get_vt when they do not come from ovg_qkv)."""
     nq_pad, nk_pad = pad_to(nq, KV_TILE), pad_to(nk, KV_TILE)
     q = torch.zeros(BH, nq_pad, D, device=device, dtype=dtype)
     k = torch.zeros(BH, nk_pad, D, device=device, dtype=dtype)

@@ -44,7 +44,7 @@ def attn(args):
             q, k, vt = ops.alloc_qkv(BH, n, n, dt, DEV)
             q[:, :n] = (torch.randn(BH, n, 64, generator=g) * 1.3).to(dt).to(DEV)
             k[:, :n] = torch.randn(BH, n, 64, generator=g).to(dt).to(DEV)
-            vt[:, :, :n] = torch.randn(BH, 64, n, generator=g).to(dt).to(DEV)
+            ops.set_vt(vt, torch.randn(BH, 64, n, generator=g).to(dt))
             flop = 4.0 * BH * n * n * 64
             ref = ops.flash_attn(q, [(k, vt, n)], n, dt, variant=1).float()
             outs = {}

@@ -188,8 +188,8 @@ def test_qkv(quick):
                 tol = TOL[name] * (2 if name != "f32" else 5)
                 report("qkv_%s_%s_%s.q" % (name, mode, vn), q[:, :seq], qr.reshape(BH, seq, 64), tol)
                 report("qkv_%s_%s_%s.k" % (name, mode, vn), k[:, :seq], kr.reshape(BH, seq, 64), tol)
-                report("qkv_%s_%s_%s.vt" % (name, mode, vn), vt[:, :, :seq], vr.reshape(BH, seq, 64).transpose(1, 2), tol)
-                pad_clean = float(q[:, seq:].abs().max()) == 0.0 and float(vt[:, :, seq:].abs().max()) == 0.0
+                report("qkv_%s_%s_%s.vt" % (name, mode, vn), ops.get_vt(vt)[:, :, :seq], vr.reshape(BH, seq, 64).transpose(1, 2), tol)
+                pad_clean = float(q[:, seq:].abs().max()) == 0.0 and float(ops.get_vt(vt)[:, :, seq:].abs().max()) == 0.0
                 if not pad_clean:
                     print("[FAIL] qkv padding was written")
             if quick:
@@ -202,7 +202,7 @@ def attn_reference(q, k, v):
     return torch.softmax(s, dim=-1) @ v
 
 
-ATTN16_VARIANTS = (0, 1, 2, 6, 8, 21, 25, 18, 19, 33)   # default, baseline QB1/2, lazy QB4/2, speculative QB4/2, forced fallback QB4/2, 512-row tiles
+ATTN16_VARIANTS = (0, 1, 2, 6, 8, 21, 25, 18, 19, 33, 50, 51, 52, 53, 54, 55)   # default, baseline QB1/2, register-staged lazy QB4/2, speculative QB4/2, forced fallback QB4/2, 512-row tiles; LDS-DMA staged: speculative 256/512-row, lazy 256, forced fallback, speculative / lazy 128-row
 
 
 def test_attn(quick):
@@ -226,7 +226,7 @@ def test_attn(quick):
                 nk = kk.shape[1]
                 _, kd, vtd = ops.alloc_qkv(BH, 64, nk, dt, DEV)
                 kd[:, :nk] = kk.to(DEV)
-                vtd[:, :, :nk] = vv.transpose(1, 2).to(DEV)
+                ops.set_vt(vtd, vv.transpose(1, 2))
                 segs.append((kd, vtd, nk))
             for variant in variants:
                 out = ops.flash_attn(qd, segs, nq, dt, variant=variant)
@@ -246,9 +246,9 @@ def test_attn(quick):
             for kk, vv in zip(ks, vs):
                 _, kd, vtd = ops.alloc_qkv(hpr, 64, nk, dt, DEV)
                 kd[:, :nk] = kk.to(DEV)
-                vtd[:, :, :nk] = vv.transpose(1, 2).to(DEV)
+                ops.set_vt(vtd, vv.transpose(1, 2))
                 segs.append((kd, vtd, nk))
-            for variant in (0, 1, 6, 21, 18, 33):
+            for variant in (0, 1, 6, 21, 18, 33, 50, 51, 52, 53):
                 out = ops.flash_attn(qd, segs, nq, dt, variant=variant, kv_heads=hpr, head_major=True)
                 report("attn_%s_headpar_v%d" % (name, variant), out[:, :nq], ref, TOL[name])
             tok = ops.heads_to_tokens(out, nq, dt)
@@ -270,7 +270,7 @@ def test_attn(quick):
             qd, kd, vtd = ops.alloc_qkv(BH, nq, nk, dt, DEV)
             qd[:, :nq] = q.to(DEV)
             kd[:, :nk] = k.to(DEV)
-            vtd[:, :, :nk] = v.transpose(1, 2).to(DEV)
+            ops.set_vt(vtd, v.transpose(1, 2))
             for variant in ((1,) if name == "f32" else ATTN16_VARIANTS):
                 out = ops.flash_attn(qd, [(kd, vtd, nk)], nq, dt, variant=variant)
                 report("attn_%s_%s_rescale_v%d" % (name, cname, variant), out, ref, TOL[name])
@@ -553,8 +553,8 @@ def test_gemm256(quick, tile=None, auto_is=True):
             ops.qkv(xd, wd, bd, seq, dt, q, k, vt, qk_norm=qnd, rope=(cos16, sin16), tile=T256)
             report("qkv256_%s_%s.q" % (name, mode), q[:, :seq], qr.reshape(BH, seq, 64), tol)
             report("qkv256_%s_%s.k" % (name, mode), k[:, :seq], kr.reshape(BH, seq, 64), tol)
-            report("qkv256_%s_%s.vt" % (name, mode), vt[:, :, :seq], vr.reshape(BH, seq, 64).transpose(1, 2), tol)
-            ok_pad = float(q[:, seq:].abs().max()) == 0.0 and float(k[:, seq:].abs().max()) == 0.0 and float(vt[:, :, seq:].abs().max()) == 0.0
+            report("qkv256_%s_%s.vt" % (name, mode), ops.get_vt(vt)[:, :, :seq], vr.reshape(BH, seq, 64).transpose(1, 2), tol)
+            ok_pad = float(q[:, seq:].abs().max()) == 0.0 and float(k[:, seq:].abs().max()) == 0.0 and float(ops.get_vt(vt)[:, :, seq:].abs().max()) == 0.0
             results.append({"name": "qkv256_%s_%s.padding_untouched" % (name, mode), "ok": ok_pad, "rel": 0.0})
             if not ok_pad:
                 print("[FAIL] qkv256 wrote padding rows")
@@ -584,9 +584,9 @@ def test_attn_big(quick):
     a 256-row tile boundary, rows spread over every XCD's share of the grid -- plus a float64 CPU evaluation of a few
     rows for independence from the device BLAS. Variants: default (speculative), lazy-rescale, forced fallback."""
     g = torch.Generator().manual_seed(17)
-    cases = [("bf16", torch.bfloat16, 8, (0, 6, 18, 33)), ("f16", torch.float16, 8, (0, 21)), ("bf16", torch.bfloat16, 16, (0,))]
+    cases = [("bf16", torch.bfloat16, 8, (0, 6, 18, 33, 51, 52, 53)), ("f16", torch.float16, 8, (0, 21, 50)), ("bf16", torch.bfloat16, 16, (0,))]
     if not quick:
-        cases.append(("bf16", torch.bfloat16, 64, (0, 6, 18, 21, 33)))
+        cases.append(("bf16", torch.bfloat16, 64, (0, 6, 18, 21, 33, 50, 53)))
         cases.append(("f16", torch.float16, 64, (0,)))
     for name, dt, S, variants in cases:
         n = S * 1374
@@ -595,7 +595,7 @@ def test_attn_big(quick):
         q[:, :n] = (torch.randn(BH, n, 64, generator=g) * 1.2).to(dt).to(DEV)
         k[:, :n] = torch.randn(BH, n, 64, generator=g).to(dt).to(DEV)
         v = torch.randn(BH, n, 64, generator=g).to(dt).to(DEV)
-        vt[:, :, :n] = v.transpose(1, 2)
+        ops.set_vt(vt, v.transpose(1, 2))
         if S <= 16:
             rows = torch.arange(n, device=DEV)
         else:
@@ -635,9 +635,9 @@ def test_attn_lse_merge():
         qd, kad, vtad = ops.alloc_qkv(BH, nq, nka, dt, DEV)
         _, kbd, vtbd = ops.alloc_qkv(BH, 64, nkb, dt, DEV)
         qd[:, :nq] = q.to(DEV)
-        kad[:, :nka] = ka.to(DEV); vtad[:, :, :nka] = va.transpose(1, 2).to(DEV)
-        kbd[:, :nkb] = kb.to(DEV); vtbd[:, :, :nkb] = vb.transpose(1, 2).to(DEV)
-        for variant in ((1,) if name == "f32" else (0, 1, 6, 21, 18, 33)):
+        kad[:, :nka] = ka.to(DEV); ops.set_vt(vtad, va.transpose(1, 2))
+        kbd[:, :nkb] = kb.to(DEV); ops.set_vt(vtbd, vb.transpose(1, 2))
+        for variant in ((1,) if name == "f32" else (0, 1, 6, 21, 18, 33, 51, 52, 53)):
             la = torch.full((BH, qd.shape[1]), float("nan"), device=DEV)
             lb = torch.full((BH, qd.shape[1]), float("nan"), device=DEV)
             oa = ops.flash_attn(qd, [(kad, vtad, nka)], nq, dt, variant=variant, lse=la)
@@ -663,9 +663,9 @@ def test_attn_lse_merge():
             nk = kk.shape[1]
             _, kd, vtd = ops.alloc_qkv(BH, 64, nk, dt, DEV)
             kd[:, :nk] = kk.to(DEV)
-            vtd[:, :, :nk] = vv.transpose(1, 2).to(DEV)
+            ops.set_vt(vtd, vv.transpose(1, 2))
             segs.append((kd, vtd, nk))
-        for variant in (0, 6, 18, 33):
+        for variant in (0, 6, 18, 33, 50, 51, 52, 53):
             for splits in (0, 2, 3, 5, 8):
                 plan = ops.attn_plan(BH, nq, nks, dt, variant, splits, nq_pad=qd.shape[1])
                 ws = ops.alloc_split_ws(plan, DEV)
@@ -769,7 +769,7 @@ def microbench():
             q, k, vt = ops.alloc_qkv(BH, n, n, dt, DEV)
             q[:, :n] = rnd(BH, n, 64, g=g).to(dt).to(DEV)
             k[:, :n] = rnd(BH, n, 64, g=g).to(dt).to(DEV)
-            vt[:, :, :n] = rnd(BH, 64, n, g=g).to(dt).to(DEV)
+            ops.set_vt(vt, rnd(BH, 64, n, g=g).to(dt))
             o = torch.empty(n, 1024, device=DEV, dtype=dt)
             ms = bench(lambda: ops.flash_attn(q, [(k, vt, n)], n, dt, out=o, variant=variant), iters=5)
             tf = 4.0 * n * n * 1024 / ms / 1e9
@@ -781,7 +781,7 @@ def microbench():
             q, k, vt = ops.alloc_qkv(BH, n, n, dt, DEV)
             q[:, :n] = rnd(BH, n, 64, g=g).to(dt).to(DEV)
             k[:, :n] = rnd(BH, n, 64, g=g).to(dt).to(DEV)
-            vt[:, :, :n] = rnd(BH, 64, n, g=g).to(dt).to(DEV)
+            ops.set_vt(vt, rnd(BH, 64, n, g=g).to(dt))
             o = torch.empty(S * n, 1024, device=DEV, dtype=dt)
             ms = bench(lambda: ops.flash_attn(q, [(k, vt, n)], n, dt, out=o, variant=variant), iters=5)
             tf = 4.0 * BH * n * n * 64 / ms / 1e9
