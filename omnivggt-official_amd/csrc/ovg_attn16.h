@@ -111,7 +111,7 @@ OVG_DEV void lds_dma16(const void* gsrc, uint32_t lds_dst) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_dst), "v"(gsrc) : "memory");
 }
 
-template <typename T, int QB, int WAVES, int SM, bool VSUM = false, bool DMA = false>   // VSUM: row sums on the VALU (experiment, variant 31) instead of the ones-MFMA; DMA: K / V^T tiles by LDS-DMA into a 3-slot ring, two tiles ahead
+template <typename T, int QB, int WAVES, int SM, bool VSUM = false, int DMA = 0>   // VSUM: row sums on the VALU (experiment, variant 31) instead of the ones-MFMA; DMA: 0 = register staging, R = 2 B + 1 (3, 5, 7, 9): K / V^T tiles by LDS-DMA into a ring of R slots, B + 1 tiles ahead, one workgroup barrier every B tiles
 OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int bh, const int q0, const int t_begin, const int total_tiles,
                        f32x4 (&o)[QB][4], f32x4 (&lacc)[QB], f32x4 (&negm)[QB]) {   // key tiles [t_begin, t_begin + total_tiles) of the flattened segment list
   constexpr int NT = 64 * WAVES;
@@ -148,7 +148,12 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
   // counted s_waitcnt vmcnt(NDMA) before the barrier means "everything but the newest tile has landed".
   //   lane l of a transfer -> LDS row l / 8, chunk position l % 8 of that row <- source chunk (l % 8) ^ swizzle(row), i.e. the LDS image
   //   is the XOR-swizzled tile the fragment reads expect (K rows = keys, V^T rows = features with the vt_pos16 key order).
-  constexpr int SLOT_B = KT_B + VT_B, NDMA = 2 * (8 / WAVES);
+  //   Barrier period B = (DMA - 1) / 2: the waves only meet every B tiles (between barriers they drift apart by up to B tiles, so
+  //   their MFMA-heavy and exp-heavy phases stop coinciding). At the barrier after tile j - 1 (j = 0 mod B) the tiles j .. j + B - 1
+  //   must have landed: with the transfers issued B + 1 tiles ahead that is "all but the newest tile" = vmcnt(NDMA). A slot is
+  //   rewritten (tile j + B + 1 -> the slot of tile j - B) only after a barrier that follows the last read of tile j - B: R >= 2 B + 1.
+  constexpr int SLOT_B = KT_B + VT_B, NDMA = 2 * (8 / WAVES), BARP = DMA ? (DMA - 1) / 2 : 1;
+  static_assert(DMA == 0 || (DMA == 2 * BARP + 1 && BARP >= 1), "ring = 2 * barrier period + 1");
   u32x4 rk[DMA ? 1 : CPT], rv[DMA ? 1 : CPT];
   int k_goff[CPT], v_row[CPT], v_coff[CPT], k_loff[CPT], v_loff[CPT];
 #pragma unroll
@@ -227,9 +232,9 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
   const int coff0 = ((0 + g) ^ sx) << 4, coff1 = ((4 + g) ^ sx) << 4;
 
   if constexpr (DMA) {
-    dma_issue(0);
-    dma_issue(1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");     // tile 0 has landed (this wave's share), tile 1 may be in flight
+#pragma unroll
+    for (int t = 0; t < BARP + 1; ++t) dma_issue(t);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");     // tiles 0 .. B - 1 have landed (this wave's share), tile B may be in flight
     __builtin_amdgcn_s_barrier();
   } else {
     fetch();
@@ -305,11 +310,12 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
     }
   }
 
+  int since_barrier = 0;
   int buf = 0;                                     // register path: LDS buffer of tile j; DMA path: ring slot of tile j
   for (int j = 0; j < total_tiles; ++j) {
     const bool more = (j + 1) < total_tiles;
     if constexpr (DMA) {
-      dma_issue(buf == 0 ? 2 : buf - 1);             // tile j + 2 -> slot (j + 2) % 3, last read as tile j - 1 (before the previous barrier)
+      dma_issue(buf >= BARP ? buf - BARP : buf - BARP + DMA);   // tile j + B + 1 -> slot (j - B) % R
     } else {
       if (more) fetch();
     }
@@ -351,11 +357,14 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
       if (cseg < p.nseg) { c_nk = (int)p.seg[cseg].nk; c_ntiles = (c_nk + BC - 1) / BC; }
     }
     if constexpr (DMA) {
-      // this wave's share of tile j + 1 was issued one iteration ago: all but the NDMA transfers of this iteration have landed.
-      // No __syncthreads (its fence drains vmcnt), no LDS writes by the waves: a bare barrier publishes tile j + 1 and retires tile j.
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-      __builtin_amdgcn_s_barrier();
-      buf = buf == 2 ? 0 : buf + 1;
+      // every B tiles: all but the newest tile's transfers (this wave's share) have landed -> a bare barrier publishes the next B
+      // tiles and retires the last B. No __syncthreads (its fence drains vmcnt); the waves never write LDS themselves.
+      if (BARP == 1 || ++since_barrier == BARP) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        __builtin_amdgcn_s_barrier();
+        since_barrier = 0;
+      }
+      buf = buf == DMA - 1 ? 0 : buf + 1;
     } else {
       if (more) stash(buf ^ 1);
       __syncthreads();
@@ -407,11 +416,11 @@ OVG_DEV void write_out(const ovg_attn_params& p, const f32x4 (&o)[QB][4], const 
 }  // namespace attn16
 
 // MODE: 0 = speculative anchored softmax + verified fallback, 1 = lazy-rescale only, 2 = forced fallback (tests)
-template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false, bool DMA = false>   // OCC: minimum waves per SIMD the register allocation must allow
+template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false, int DMA = 0>   // OCC: minimum waves per SIMD the register allocation must allow
 __global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params p, int nqt, int total_tiles, int splits, int per_split) {
   static_assert(sizeof(T) == 2, "16-bit types only");
   constexpr int RB = 128, KT_B = BC * RB, VT_B = OVG_D * RB, BQ = 16 * QB * WAVES;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[(DMA ? 3 : 2) * (KT_B + VT_B)];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(DMA ? DMA : 2) * (KT_B + VT_B)];
 
   const int tid = threadIdx.x, wave = tid >> 6;
   // logical id -> (batch entry, key split, q tile), q tile fastest: the workgroups that run side by side on an XCD share
