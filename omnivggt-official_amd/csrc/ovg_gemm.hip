@@ -578,14 +578,16 @@ int launch_linear256(const ovg_linear_params& p, hipStream_t st) {
 // 128 x 128 everywhere (44.4 vs 45.7 ms, profiles/r02_gemm_tile_in_situ.txt) -- the global-attention launches that follow
 // the denser 256 x 256 GEMMs run 9 % slower (0.533 vs 0.488 ms: the chip is power-limited, rocprofv3 shows the GEMMs at
 // 1.8-1.9 GHz and attention at 2.1-2.2 GHz, and the GEMMs' own in-situ gain shrinks with cold L2s and one workgroup per
-// CU). So the 256 x 256 kernels are used from M >= 32 768 rows (24 views), where they are worth +2 % on the 64-view forward.
+// CU). Re-measured with the LDS-DMA attention kernels (profiles/r02_gemm_tile_in_situ.txt, second block): 8 views 190.1 (128 x 128) vs
+// 189.0 frames/s, 16 views + aux 155.5 vs 156.8 (256 x 256) -- so the 256 x 256 kernels are used from M >= 20 000 rows (16 views) on,
+// where they are worth +1 % (16 views) ... +2 % (64 views) on the forward.
 // Returns 1 = use 256^2, 0 = use 128^2, -1 = the caller forced a tile this shape / dtype cannot run.
 int choose_256(int tile, bool sixteen_bit, int64_t M, int64_t N, int64_t K, bool light_epilogue_or_long_k) {
   const bool legal = sixteen_bit && N % g256::BN2 == 0 && K % 32 == 0;
   if (tile == OVG_TILE_128) return 0;
   if (tile == OVG_TILE_256) return legal ? 1 : -1;
   if (tile != OVG_TILE_AUTO) return -1;
-  if (!legal || !light_epilogue_or_long_k || M < 32768) return 0;
+  if (!legal || !light_epilogue_or_long_k || M < 20000) return 0;
   return 1;
 }
 

@@ -243,3 +243,21 @@ def test_integration_path_a_state_dict_swap_into_the_reference_model():
     with pytest.raises(L.OvgError):                              # and it fails loudly without a HIP device (no silent CPU path)
         ref(torch.zeros(1, 2, 3, 518, 518), torch.zeros(1, 2, 3, 4), torch.zeros(1, 2, 3, 3), torch.zeros(1, 2, 518, 518, 1),
             torch.zeros(1, 2, 518, 518), [], [])
+
+
+def test_vt_column_order_helpers():
+    """16-bit V^T rows hold their keys in the PV fragment order (include/omnivggt_hip.h, ovg_qkv): inside every 32-key block column
+    8 g + 4 h + i holds key 16 h + 4 g + i; f32 rows are natural. ops.set_vt / get_vt are the converters tests and external callers use."""
+    from omnivggt_official_amd import ops
+    idx = ops.vt_index(64, torch.bfloat16)
+    assert idx[:32].tolist() == [0, 1, 2, 3, 16, 17, 18, 19, 4, 5, 6, 7, 20, 21, 22, 23, 8, 9, 10, 11, 24, 25, 26, 27, 12, 13, 14, 15, 28, 29, 30, 31]
+    assert idx[32:].tolist() == [32 + k for k in idx[:32].tolist()]
+    for g in range(4):                                   # every 16-byte chunk = keys {4g..4g+3, 16+4g..16+4g+3}: one lane group's fragment
+        assert idx[8 * g: 8 * g + 8].tolist() == [4 * g + i for i in range(4)] + [16 + 4 * g + i for i in range(4)]
+    assert torch.equal(ops.vt_index(64, torch.float32), torch.arange(64))
+    v = torch.arange(2 * 64 * 70, dtype=torch.float32).reshape(2, 64, 70)
+    for dt in (torch.bfloat16, torch.float16, torch.float32):
+        vt = torch.zeros(2, 64, 128, dtype=dt)
+        ops.set_vt(vt, v.to(dt))
+        nat = ops.get_vt(vt)
+        assert torch.equal(nat[:, :, :70], v.to(dt)) and float(nat[:, :, 70:].abs().max()) == 0.0
