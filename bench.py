@@ -45,8 +45,8 @@ from omnivggt_official_amd.model import OmniVGGT  # noqa: E402
 P_TOK, C = 1374, 1024
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}     # MI355X_MICROARCH.md, dense MFMA
 DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
-KERNEL_NAME = {"bf16": "attn16_kernel<bf16,QB=4,WAVES=%d,MODE=0> (speculative anchored softmax + verified fallback; %d-row q tiles)",
-               "f16": "attn16_kernel<f16,QB=4,WAVES=%d,MODE=1> (lazy-rescale online softmax; %d-row q tiles)",
+KERNEL_NAME = {"bf16": "attn16_kernel<bf16,QB=4,WAVES=%d,MODE=0> (speculative anchored softmax + verified fallback; K/V^T tiles by LDS-DMA; %d-row q tiles)",
+               "f16": "attn16_kernel<f16,QB=4,WAVES=%d,MODE=1> (lazy-rescale online softmax; K/V^T tiles by LDS-DMA; %d-row q tiles)",
                "f32": "attn_kernel<float,QB=1> (exact-f32 MFMA 16x16x4, classic online softmax)"}
 
 
@@ -56,7 +56,7 @@ def kernel_name(dtype_name, n_q, n_k):
         return KERNEL_NAME["f32"]
     from omnivggt_official_amd import ops
     plan = ops.attn_plan(16, n_q, [n_k], DT[dtype_name])
-    name = KERNEL_NAME[dtype_name] % (plan["q_tile"] // 64, plan["q_tile"])
+    name = KERNEL_NAME[dtype_name] % (min(plan["q_tile"] // 64, 8), plan["q_tile"])
     return name + (", split-KV x%d" % plan["splits"] if plan["splits"] > 1 else "")
 PARITY_LAYERS = (0, 4, 11, 17, 23)
 
