@@ -299,15 +299,15 @@ Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
   const int64_t units512 = p.BH * ((p.nq + 511) / 512);
   // 512-row tiles (8 waves, one workgroup per CU, barrier every 2 tiles) from ~2.5 rounds of them on: 16 views +5.9 %, 64 views +3 %
   // over the 256-row kernel; below that the coarser tiles quantise worse than they gain (8 views: -17 %)
-  if (v == 0) v = bf16 ? (2 * units512 >= 5 * (int64_t)cus ? 57 : 50) : (2 * units512 >= 5 * (int64_t)cus ? 62 : (p.nq >= 4096 ? 52 : 55));
+  if (v == 0) v = bf16 ? (2 * units512 >= 5 * (int64_t)cus ? 57 : 50) : (p.nq >= 4096 ? 52 : 55);
   pl.variant = v;
-  pl.bq = (v == 33 || v == 51 || v == 57 || v == 58 || v == 59 || v == 62) ? 512 : ((v == 8 || v == 25 || v == 19 || v == 54 || v == 55) ? 128 : 256);
+  pl.bq = (v == 33 || v == 51 || v == 57 || v == 58 || v == 59) ? 512 : ((v == 8 || v == 25 || v == 19 || v == 54 || v == 55) ? 128 : 256);
   pl.total_tiles = total_key_tiles(p);
-  const int slots = (v == 33 || v == 51 || v == 57 || v == 58 || v == 59 || v == 62) ? cus : 2 * cus;
+  const int slots = (v == 33 || v == 51 || v == 57 || v == 58 || v == 59) ? cus : 2 * cus;
   const int64_t units = p.BH * ((p.nq + pl.bq - 1) / pl.bq);
   int splits = 1;
   if (p.kv_splits > 1) splits = p.kv_splits;
-  else if (p.kv_splits == 0 && have_ws && (v == 21 || v == 6 || v == 33 || v == 50 || v == 51 || v == 52 || v == 57 || v == 62)) {
+  else if (p.kv_splits == 0 && have_ws && (v == 21 || v == 6 || v == 33 || v == 50 || v == 51 || v == 52 || v == 57)) {
     // Measured model (profiles/r02_attention_splitkv_ab.txt): a launch of R = units / slots rounds runs at eff(R) = 1 - 0.155 / R^1.2
     // of the many-round rate (0.89 at R = 1.34, 0.95 at 2.7, 0.98 at 5.4: the tail rounds run with fewer co-resident
     // workgroups and are faster than a full one, so the loss is smaller than ceil(R) / R); a split costs ~1.5 key tiles per
@@ -361,8 +361,8 @@ int launch_attn16(const ovg_attn_params& p, const Plan16& pl, hipStream_t st) {
 //   33      8 waves x 64 rows = 512-row q tiles, 1 workgroup per CU, register-staged (the r02 default for launches of >= 8 rounds)
 //   50 / 51 / 54   LDS-DMA staging (3-slot ring, two tiles ahead, barrier per tile): speculative kernel with 256- / 512- / 128-row q tiles;
 //                  50 = the bf16 default for short launches
-//   52 / 55 / 62   LDS-DMA staging, lazy-rescale kernel, 256- / 128- / 512-row (barrier every 2 tiles) q tiles -- the f16 defaults
-//                  (62 from 2.5 rounds of 512-row tiles on, else 52 for nq >= 4096, else 55)
+//   52 / 55        LDS-DMA staging, lazy-rescale kernel, 256- / 128-row q tiles -- the f16 default (52 for nq >= 4096, else 55; a 512-row
+//                  8-wave form of the lazy-rescale body measured 4 % slower at 64 views: profiles/r02_attention_dma_ab.txt)
 //   53             LDS-DMA staging with the fallback forced (tests)
 //   57 / 58 / 59   as 51 with a workgroup barrier only every 2 / 3 / 4 tiles (ring of 5 / 7 / 9 slots): 57 = the bf16 default for launches of
 //                  >= 2.5 rounds of 512-row tiles; 56 = the 4-wave kernel with a 5-slot ring (80 KB: one workgroup per CU, A/B only)
@@ -391,7 +391,6 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
     case 55: return launch_attn16<T, 2, 4, 1, 2, false, 3>(p, pl, st);
     case 56: return launch_attn16<T, 4, 4, 0, 2, false, 5>(p, pl, st);
     case 57: return launch_attn16<T, 4, 8, 0, 2, false, 5>(p, pl, st);
-    case 62: return launch_attn16<T, 4, 8, 1, 2, false, 5>(p, pl, st);
     case 58: return launch_attn16<T, 4, 8, 0, 2, false, 7>(p, pl, st);
     case 59: return launch_attn16<T, 4, 8, 0, 2, false, 9>(p, pl, st);
     default: return OVG_E_ARG;

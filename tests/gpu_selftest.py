@@ -202,7 +202,7 @@ def attn_reference(q, k, v):
     return torch.softmax(s, dim=-1) @ v
 
 
-ATTN16_VARIANTS = (0, 1, 2, 6, 8, 21, 25, 18, 19, 33, 50, 51, 52, 53, 54, 55, 57, 58, 62)   # default, baseline QB1/2, register-staged lazy QB4/2, speculative QB4/2, forced fallback QB4/2, 512-row tiles; LDS-DMA staged: speculative 256/512-row, lazy 256, forced fallback, speculative / lazy 128-row, 512-row with a barrier every 2 / 3 tiles
+ATTN16_VARIANTS = (0, 1, 2, 6, 8, 21, 25, 18, 19, 33, 50, 51, 52, 53, 54, 55, 57, 58)   # default, baseline QB1/2, register-staged lazy QB4/2, speculative QB4/2, forced fallback QB4/2, 512-row tiles; LDS-DMA staged: speculative 256/512-row, lazy 256, forced fallback, speculative / lazy 128-row, 512-row with a barrier every 2 / 3 tiles
 
 
 def test_attn(quick):
@@ -584,7 +584,7 @@ def test_attn_big(quick):
     a 256-row tile boundary, rows spread over every XCD's share of the grid -- plus a float64 CPU evaluation of a few
     rows for independence from the device BLAS. Variants: default (speculative), lazy-rescale, forced fallback."""
     g = torch.Generator().manual_seed(17)
-    cases = [("bf16", torch.bfloat16, 8, (0, 6, 18, 33, 51, 52, 53, 57)), ("f16", torch.float16, 8, (0, 21, 50, 62)), ("bf16", torch.bfloat16, 16, (0,))]
+    cases = [("bf16", torch.bfloat16, 8, (0, 6, 18, 33, 51, 52, 53, 57)), ("f16", torch.float16, 8, (0, 21, 50)), ("bf16", torch.bfloat16, 16, (0,))]
     if not quick:
         cases.append(("bf16", torch.bfloat16, 64, (0, 6, 18, 21, 33, 50, 53, 59)))
         cases.append(("f16", torch.float16, 64, (0,)))
@@ -665,7 +665,7 @@ def test_attn_lse_merge():
             kd[:, :nk] = kk.to(DEV)
             ops.set_vt(vtd, vv.transpose(1, 2))
             segs.append((kd, vtd, nk))
-        for variant in (0, 6, 18, 33, 50, 51, 52, 53, 57, 62):
+        for variant in (0, 6, 18, 33, 50, 51, 52, 53, 57):
             for splits in (0, 2, 3, 5, 8):
                 plan = ops.attn_plan(BH, nq, nks, dt, variant, splits, nq_pad=qd.shape[1])
                 ws = ops.alloc_split_ws(plan, DEV)
