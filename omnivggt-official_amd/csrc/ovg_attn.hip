@@ -299,7 +299,14 @@ Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
   const int64_t units512 = p.BH * ((p.nq + 511) / 512);
   // 512-row tiles (8 waves, one workgroup per CU, barrier every 2 tiles) from ~2.5 rounds of them on: 16 views +5.9 %, 64 views +3 %
   // over the 256-row kernel; below that the coarser tiles quantise worse than they gain (8 views: -17 %)
-  if (v == 0) v = bf16 ? (2 * units512 >= 5 * (int64_t)cus ? 57 : 50) : (p.nq >= 4096 ? 52 : 55);
+  // short sequences (frame-local attention, 1374 rows): the tile that pads the sequence least wins -- 11 x 128 = 1408 rows against
+  // 6 x 256 = 3 x 512 = 1536 (64 views: 0.521 ms with 128-row tiles, 0.537 with 256-row, 0.556 with 512-row)
+  if (v == 0) {
+    const int64_t pad128 = (p.nq + 127) / 128 * 128, pad256 = (p.nq + 255) / 256 * 256;
+    if (!bf16) v = p.nq >= 4096 ? 52 : 55;
+    else if (p.nq >= 4096) v = 2 * units512 >= 5 * (int64_t)cus ? 57 : 50;
+    else v = pad128 * 26 < pad256 * 25 ? 54 : 50;
+  }
   pl.variant = v;
   pl.bq = (v == 33 || v == 51 || v == 57 || v == 58 || v == 59) ? 512 : ((v == 8 || v == 25 || v == 19 || v == 54 || v == 55) ? 128 : 256);
   pl.total_tiles = total_key_tiles(p);
