@@ -295,6 +295,7 @@ int total_key_tiles(const ovg_attn_params& p) {
 Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
   Plan16 pl{};
   int v = p.variant;
+  if (v == 71) v = 57;            // A/B tool: the 512-row kernel with its tail split (dispatch16)
   const int cus = cu_count_attn();
   const int64_t units512 = p.BH * ((p.nq + 511) / 512);
   // 512-row tiles (8 waves, one workgroup per CU, barrier every 2 tiles) from ~2.5 rounds of them on: 16 views +5.9 %, 64 views +3 %
@@ -343,11 +344,12 @@ Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
 }
 
 template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false, int DMA = 0>
-int launch_attn16(const ovg_attn_params& p, const Plan16& pl, hipStream_t st) {
+int launch_attn16(const ovg_attn_params& p, const Plan16& pl, hipStream_t st, int64_t row0 = 0, int64_t row1 = -1) {   // q rows [row0, row1) (default: all)
   constexpr int BQ = 16 * QB * WAVES;
-  const int nqt = (int)((p.nq + BQ - 1) / BQ);
+  if (row1 < 0) row1 = p.nq;
+  const int nqt = (int)((row1 - row0 + BQ - 1) / BQ);
   const dim3 grid((unsigned)(p.BH * nqt * pl.splits)), block(64 * WAVES);
-  OVG_LAUNCH((attn16_kernel<T, QB, WAVES, MODE, OCC, VSUM, DMA>), grid, block, 0, st, p, nqt, pl.total_tiles, pl.splits, pl.per_split);
+  OVG_LAUNCH((attn16_kernel<T, QB, WAVES, MODE, OCC, VSUM, DMA>), grid, block, 0, st, p, nqt, pl.total_tiles, pl.splits, pl.per_split, (int)row0);
   OVG_CHECK_LAUNCH();
   if (pl.splits > 1) {
     const int64_t total = p.BH * p.nq * 8;
@@ -378,6 +380,23 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
   constexpr bool kBf16 = std::is_same<T, bf16_t>::value;
   const Plan16 pl = plan16(p, kBf16, p.ws_part != nullptr && p.ws_lse != nullptr);
   if (pl.splits > 1 && (p.ws_part == nullptr || p.ws_lse == nullptr)) return OVG_E_ARG;
+  // Tail split of the 512-row kernel (automatic plan; variant 71 forces it for the A/B tool): a launch of R = units / 256 rounds pays
+  // a whole round -- or more: one workgroup per CU, nothing to overlap with -- for its fractional last one (tools/probes/attn_tail_probe.py,
+  // 64 views: 22.18 ms for 10.0 rounds, 24.91 ms for 10.75: +4.6 % per row). The full rounds keep the 512-row tiles; the remaining rows of
+  // every head go to a second launch of 128-row tiles (three workgroups per CU) that spreads them over the whole chip. Measured
+  // (profiles/r02_attention_dma_ab.txt): 16 / 24 / 32 / 48 / 64 views +1.5 / +11.5 / +7.6 / +4.1 / +1.5 % over the unsplit 512-row launch and
+  // best-or-within-1.3 % of the best of {256-row, 512-row} x {split, unsplit} at every size.
+  if ((p.variant == 0 || p.variant == 71) && pl.splits == 1 && pl.variant == 57) {
+    const int slots = cu_count_attn();
+    const int64_t units = p.BH * ((p.nq + pl.bq - 1) / pl.bq);
+    const int64_t full = units / slots;
+    const double frac = (double)units / slots - (double)full;
+    const int64_t rows_a = full * slots / p.BH * pl.bq;
+    if (full >= 2 && frac > 0.05 && frac < 0.85 && rows_a > 0 && rows_a < p.nq) {
+      const int rc = launch_attn16<T, 4, 8, 0, 2, false, 5>(p, pl, st, 0, rows_a);
+      return rc != OVG_OK ? rc : launch_attn16<T, 2, 4, 0, 2, false, 3>(p, pl, st, rows_a, p.nq);
+    }
+  }
   switch (pl.variant) {
     case 1: return launch_attn<T, 1>(p, st);
     case 2: return launch_attn<T, 2>(p, st);

@@ -417,7 +417,7 @@ OVG_DEV void write_out(const ovg_attn_params& p, const f32x4 (&o)[QB][4], const 
 
 // MODE: 0 = speculative anchored softmax + verified fallback, 1 = lazy-rescale only, 2 = forced fallback (tests)
 template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false, int DMA = 0>   // OCC: minimum waves per SIMD the register allocation must allow
-__global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params p, int nqt, int total_tiles, int splits, int per_split) {
+__global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params p, int nqt, int total_tiles, int splits, int per_split, int q_row0) {   // q tiles [0, nqt) of the rows starting at q_row0
   static_assert(sizeof(T) == 2, "16-bit types only");
   constexpr int RB = 128, KT_B = BC * RB, VT_B = OVG_D * RB, BQ = 16 * QB * WAVES;
   __shared__ __attribute__((aligned(16))) unsigned char lds[(DMA ? DMA : 2) * (KT_B + VT_B)];
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int qt = lid % nqt, rest = lid / nqt;
   const int sp = rest % splits, bh = rest / splits;
-  const int q0 = qt * BQ + wave * 16 * QB;
+  const int q0 = q_row0 + qt * BQ + wave * 16 * QB;
   const int t0 = sp * per_split;
   const int nt = (total_tiles - t0) < per_split ? (total_tiles - t0) : per_split;   // >= 1: the host sizes splits so that every pass has keys
 
