@@ -315,25 +315,27 @@ Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
   const int64_t units = p.BH * ((p.nq + pl.bq - 1) / pl.bq);
   int splits = 1;
   if (p.kv_splits > 1) splits = p.kv_splits;
-  else if (p.kv_splits == 0 && have_ws && (v == 21 || v == 6 || v == 33 || v == 50 || v == 51 || v == 52 || v == 57)) {
-    // Measured model (profiles/r02_attention_splitkv_ab.txt): a launch of R = units / slots rounds runs at eff(R) = 1 - 0.155 / R^1.2
-    // of the many-round rate (0.89 at R = 1.34, 0.95 at 2.7, 0.98 at 5.4: the tail rounds run with fewer co-resident
-    // workgroups and are faster than a full one, so the loss is smaller than ceil(R) / R); a split costs ~1.5 key tiles per
-    // unit plus the partial results' round trip through HBM (in situ ~2.5 TB/s for the write + read-back). Split only for a
-    // >= 3 % estimated gain: single-GPU launches never qualify (8 views: the 90 MB of partials cost what the split gains),
-    // the per-rank launches of the view-sharded run (8 views of queries x 64 views of keys) gain ~7 % at 4 splits.
+  else if (p.kv_splits == 0 && have_ws && (v == 21 || v == 6 || v == 50 || v == 52 || v == 54 || v == 55)) {   // two-workgroups-per-CU kernels (the 512-row ones have the tail split)
+    // Measured model (LDS-DMA kernels, profiles/r02_attention_splitkv_ab.txt second block): a launch of R = units / slots rounds runs at
+    // eff(R) = 1 - 0.2035 / R^0.72 of the many-round rate of 1.33 PFLOP/s (0.835 at R = 1.34, 0.88-0.90 at 2.7, 0.94-0.95 at 5.4, 0.963 at
+    // 10.75: measured at 8 / 16 / 32 / 64 views and on the per-rank launch of the 8-GPU run); a split costs ~1.5 key tiles per unit plus the
+    // partial results' round trip through HBM (in situ ~2.5 TB/s for the write + read-back). Single-GPU launches never qualify (8 views: the
+    // partials cost 17 % of the launch); the per-rank launches of the view-sharded run (8 views of queries x 64 views of keys: 3.57 ms unsplit,
+    // 3.43 ms at 2 splits, 3.15 ms at 4) take 4 splits.
     double nk_total = 0;
     for (int i = 0; i < p.nseg; ++i) nk_total += (double)p.seg[i].nk;
-    const double t0 = 4.0 * p.BH * (double)p.nq * nk_total * OVG_D / 1.2e15;            // seconds at the many-round rate
-    auto eff = [](double R) { return R < 1.0 ? 0.845 * R : 1.0 - 0.155 / pow(R, 1.2); };   // below one round: idle CUs, linear
+    const double t0 = 4.0 * p.BH * (double)p.nq * nk_total * OVG_D / 1.33e15;           // seconds at the many-round rate
+    auto eff = [](double R) { return R < 1.0 ? 0.8 * R : 1.0 - 0.2035 / pow(R, 0.72); };   // below one round: idle CUs, linear
     const double R = (double)units / slots;
-    double best = t0 / eff(R);
+    const double unsplit = t0 / eff(R);
+    double best = unsplit * 0.985;                   // a split must be worth >= 1.5 %; among the splits the estimated minimum wins
     for (int s = 2; s <= OVG_MAX_SEG; ++s) {
       const int per = (pl.total_tiles + s - 1) / s;
       if (per < 16) break;
       const double part_bytes = 2.0 * s * p.BH * (double)p.nq * OVG_D * 2;
-      const double t = t0 / eff(R * s) * (1.0 + 1.5 / per) + part_bytes / 2.5e12;
-      if (t < best * 0.97) { best = t; splits = s; }
+      double t = t0 / eff(R * s) * (1.0 + 1.5 / per) + part_bytes / 2.5e12 + 8e-6;   // + the merge launch
+      if (p.nseg > 1 && p.nseg % s == 0) t *= 0.98;    // passes that end on segment boundaries (8 segments: 3.13 ms at 4 splits, 3.18 at 5, 3.49 at 3)
+      if (t < best) { best = t; splits = s; }
     }
   }
   if (splits > OVG_MAX_SEG) splits = OVG_MAX_SEG;
