@@ -5,7 +5,8 @@ sys.path.insert(0, "/root/repo")
 from omnivggt_official_amd import ops
 dt, DEV = torch.bfloat16, "cuda"
 g = torch.Generator().manual_seed(0)
-W, gs, n = 8, 2, 8 * 1374
+# usage: attn_rank_shape_probe.py [ranks heads_per_launch views_per_rank]   (default 8 2 8; 4 ranks: 4 4 16; 2 ranks, one of two head groups: 2 4 32)
+W, gs, n = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]) * 1374) if len(sys.argv) > 3 else (8, 2, 8 * 1374)
 q, _, _ = ops.alloc_qkv(W * gs, n, n, dt, DEV)
 q[:, :n] = (torch.randn(W * gs, n, 64, generator=g) * 1.3).to(dt).to(DEV)
 segs = []
@@ -17,7 +18,7 @@ for r in range(W):
 flop = 4.0 * W * gs * n * (W * n) * 64
 out = torch.empty(W * gs, q.shape[1], 64, device=DEV, dtype=dt)
 ref = None
-for variant, sp in ((50, 1), (0, 0), (50, 2), (50, 3), (50, 4), (50, 5), (50, 6), (50, 8), (54, 1), (57, 1)):
+for variant, sp in ((50, 1), (0, 0), (50, 2), (50, 4), (50, 8), (57, 1), (71, 1)):
     plan = ops.attn_plan(W * gs, n, [n] * W, dt, variant, sp, nq_pad=q.shape[1])
     ws = ops.alloc_split_ws(plan, DEV) if plan["splits"] > 1 else None
     f = lambda: ops.flash_attn(q, segs, n, dt, out=out, variant=variant, kv_heads=gs, head_major=True, kv_splits=sp, split_ws=ws)
