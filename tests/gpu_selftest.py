@@ -645,6 +645,23 @@ def test_attn_lse_merge():
             report("attn_lse_%s_v%d" % (name, variant), la[:, :nq], lse_ref_a, 2e-5 if name == "f32" else 2e-3)
             merged = ops.attn_merge(oa, la, ob, lb, dt, out=oa)          # in place on launch A's output, like sharding.py
             report("attn_merge_%s_v%d" % (name, variant), merged, ref, TOL[name] * (1.5 if name != "f32" else 1))
+    # tail split of the automatic plan (16 views = 2.69 rounds of 512-row tiles -> 512-row launch + 128-row tail launch): outputs and
+    # log-sum-exps of BOTH launches against the baseline kernel on the same device buffers, token-major and head-major
+    g2 = torch.Generator().manual_seed(23)
+    BH, n = 16, 16 * 1374
+    qd, kd, vtd = ops.alloc_qkv(BH, n, n, torch.bfloat16, DEV)
+    qd[:, :n] = (rnd(BH, n, 64, g=g2) * 1.3).to(torch.bfloat16).to(DEV)
+    kd[:, :n] = rnd(BH, n, 64, g=g2).to(torch.bfloat16).to(DEV)
+    ops.set_vt(vtd, rnd(BH, 64, n, g=g2).to(torch.bfloat16))
+    l1 = torch.full((BH, qd.shape[1]), float("nan"), device=DEV)
+    l0 = torch.full((BH, qd.shape[1]), float("nan"), device=DEV)
+    o1 = ops.flash_attn(qd, [(kd, vtd, n)], n, torch.bfloat16, variant=1, lse=l1)
+    o0 = ops.flash_attn(qd, [(kd, vtd, n)], n, torch.bfloat16, variant=0, lse=l0)
+    report("attn_tailsplit_bf16_S16_out", o0, o1, TOL["bf16"])
+    report("attn_tailsplit_bf16_S16_lse", l0[:, :n], l1[:, :n], 2e-3)
+    h0 = ops.flash_attn(qd, [(kd, vtd, n)], n, torch.bfloat16, variant=0, head_major=True)
+    report("attn_tailsplit_bf16_S16_headmajor", h0[:, :n].permute(1, 0, 2).reshape(n, 1024), o1, TOL["bf16"])
+    del qd, kd, vtd, o0, o1, h0
     # split-KV: forced 2..8 key splits (+ the library's own plan) == the single-pass result, token-major and head-major,
     # ragged multi-segment key lists, with the total log-sum-exp output
     for name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
