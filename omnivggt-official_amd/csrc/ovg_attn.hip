@@ -306,7 +306,7 @@ Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
     const int64_t pad128 = (p.nq + 127) / 128 * 128, pad256 = (p.nq + 255) / 256 * 256;
     if (!bf16) v = p.nq >= 4096 ? 52 : 55;
     else if (p.nq >= 4096) v = 2 * units512 >= 5 * (int64_t)cus ? 57 : 50;
-    else v = pad128 * 26 < pad256 * 25 ? 54 : 50;
+    else v = (pad128 * 26 < pad256 * 25 && 2 * p.BH * (pad128 / 128) >= 15 * (int64_t)cus) ? 54 : 50;   // ... from 2.5 rounds of 3 x CUs slots on (8 views: 0.069 ms with 256-row, 0.072 with 128-row tiles)
   }
   pl.variant = v;
   pl.bq = (v == 33 || v == 51 || v == 57 || v == 58 || v == 59) ? 512 : ((v == 8 || v == 25 || v == 19 || v == 54 || v == 55) ? 128 : 256);
