@@ -9,7 +9,7 @@
 // only has to keep up with the loads. So:
 //  * ch_gemm_partial: one wave = 16 weight rows x a K range, the weight fragments go global -> registers -> MFMA A operand
 //    (each element is used once per 64 tokens: no LDS staging), the S token rows are the B operand (L2 resident);
-//    split-K over enough workgroups to fill the chip (>= 256), deterministic: every split writes its own f32 partial;
+//    split-K over enough workgroups to fill the chip (>= 512 where K allows), deterministic: every split writes its own f32 partial;
 //  * the partial sums are folded by the CONSUMER: the row kernels (bias + LayerScale + residual + the next LayerNorm in one
 //    pass over the 2048-wide row), the adaLN modulation, the pose update; only QKV and fc1 have a stand-alone finish
 //    (bias / bias + exact GELU -> 16 bit);
