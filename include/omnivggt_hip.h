@@ -37,8 +37,11 @@ extern "C" {
  * 3: + head-parallel sharding (ovg_attn_params.kv_heads / out_bh_stride, ovg_block_params.skip_attention, ovg_heads_to_tokens)
  * 4: per-call GEMM tile selector (`tile`) replacing the process-global debug setter of ABI 3, optional
  *    log-sum-exp output of ovg_flash_attn + ovg_attn_merge (two-launch local-first sharded attention),
- *    ovg_block_workspace_bytes, ovg_pack_weights, split-KV attention (kv_splits / ws_part / ws_lse, ovg_attn_plan) */
-#define OVG_ABI_VERSION 6
+ *    ovg_block_workspace_bytes, ovg_pack_weights, split-KV attention (kv_splits / ws_part / ws_lse, ovg_attn_plan)
+ * 5-6: camera head entry; 16-bit V^T rows in the PV fragment order (LDS-DMA staged attention)
+ * 7: split-KV workspace SIZES travel with the pointers (ws_part_bytes / ws_lse_bytes: an undersized workspace is OVG_E_ARG
+ *    instead of an out-of-bounds write), ovg_camera_tables (camera-modality injection tables built on the device) */
+#define OVG_ABI_VERSION 7
 
 enum { OVG_BF16 = 0, OVG_F16 = 1, OVG_F32 = 2 };
 
@@ -92,7 +95,8 @@ int ovg_layernorm(const ovg_layernorm_params*, void* stream);
 enum { OVG_EPI_STORE = 0, OVG_EPI_GELU = 1, OVG_EPI_RES = 2, OVG_EPI_PATCH = 3 };
 /* workgroup tile of the GEMM kernels: 128 x 128 (4 waves, register-staged, up to 3 workgroups per CU) or 256 x 256 (8 waves,
  * LDS-DMA ring with ping-pong wave groups, 1 workgroup per CU, 16-bit dtypes); AUTO picks by shape (ovg_gemm.hip: choose_256) */
-enum { OVG_TILE_AUTO = 0, OVG_TILE_128 = 1, OVG_TILE_256 = 2 };
+enum { OVG_TILE_AUTO = 0, OVG_TILE_128 = 1, OVG_TILE_256 = 2,
+       OVG_TILE_256X = 3 /* A/B knob: the 256 x 256 kernels with the previous epilogue forms (see ovg_gemm.hip) */ };
 typedef struct {
   const void* x; int64_t ldx;
   const void* w; int64_t ldw;
@@ -173,8 +177,9 @@ typedef struct {
    * passes per unit; every pass writes a normalised partial result + its log-sum-exp into the caller's workspace and
    * a second (tiny) launch combines them exactly. kv_splits: 0 = the library decides (ovg_attn_plan; never splits
    * when ws_part / ws_lse are NULL), 1 = never, 2..8 = force. ws_part: `part_bytes`, ws_lse: `lse_bytes` of ovg_attn_plan.
-   * Units of one (batch entry, split) run next to each other, so the K / V^T range an XCD streams shrinks by kv_splits. */
-  int kv_splits; void* ws_part; float* ws_lse;
+   * Units of one (batch entry, split) run next to each other, so the K / V^T range an XCD streams shrinks by kv_splits.
+   * ws_part_bytes / ws_lse_bytes: sizes of the two buffers; a call whose plan needs more than it was given is OVG_E_ARG. */
+  int kv_splits; void* ws_part; float* ws_lse; int64_t ws_part_bytes; int64_t ws_lse_bytes;
 } ovg_attn_params;
 int ovg_flash_attn(const ovg_attn_params*, void* stream);
 
@@ -242,8 +247,8 @@ typedef struct {
   void* ev_attn_start; void* ev_attn_stop;
   int skip_attention;  /* ovg_block_attn_epilogue only: ws_attn already holds the attention output (head-parallel sharding) */
   int gemm_tile;       /* OVG_TILE_* forwarded to the four GEMMs of the block (tests force a tile; 0 in production) */
-  /* optional split-KV workspace of the block's attention launch (ovg_attn_params.ws_part / ws_lse; NULL = never split) */
-  void* ws_attn_part; float* ws_attn_lse; int attn_kv_splits;
+  /* optional split-KV workspace of the block's attention launch (ovg_attn_params.ws_part / ws_lse + their sizes; NULL = never split) */
+  void* ws_attn_part; float* ws_attn_lse; int attn_kv_splits; int64_t ws_attn_part_bytes; int64_t ws_attn_lse_bytes;
 } ovg_block_params;
 /* whole block */
 int ovg_block_forward(const ovg_block_params*, void* stream);
@@ -455,6 +460,30 @@ typedef struct {
 } ovg_camera_head_params;
 int64_t ovg_camera_head_workspace_bytes(int32_t S, int32_t dtype);
 int ovg_camera_head(const ovg_camera_head_params*, void* stream);
+
+/* ------------------------------------------------------------------
+ * Camera-modality injection tables, built on the device without a host round trip (replaces, per forward:
+ * ZeroAggregator.normalize_extrinsics omnivggt_aggregator.py:85-105 with closed_form_inverse_se3 utils/geometry.py:269-318,
+ * extri_intri_to_pose_encoding utils/pose_enc.py:11-62 with mat_to_quat utils/rotation.py:47-109, the 25 pose_embeddings /
+ * camera_adapters Linear pairs omnivggt_aggregator.py:62-75,172,211,277,286 and the zero-padded scatter :174-178,278-282):
+ *   enc[b, r]       = pose encoding (t, quat xyzw, fov_h, fov_w) of camera index[r] of batch b after normalisation
+ *                     (first selected camera -> identity, translations / mean distance of the others to it)
+ *   emb[g, b*Sc+r]  = pose_w[g] enc[b, r] + pose_b[g]                                   g < G (= depth + 1 tables)
+ *   tables[g, b*S+s] = adapt_w[g] emb[g, b*Sc+r] + adapt_b[g]   if s == index[r]        (exact-f32 MFMA)
+ *                      adapt_b[g]                               otherwise (Linear of a zero row)
+ * extrinsics [B,S,3,4] (world-to-camera), intrinsics [B,S,3,3] f32; index: DEVICE int32 [Sc], strictly the caller's
+ * camera_gt_index (values in [0, S)); pose_w [G*1024, 9] f32 row-major, pose_b [G*1024]; adapt_w [G,1024,1024] f32
+ * (nn.Linear layout, 16-byte aligned), adapt_b [G,1024]; enc [B*Sc, 9] and emb [G, B*Sc, 1024] are caller-owned scratch
+ * (NULL allowed when Sc == 0); tables [G, B*S, 1024] f32. Three launches (one when Sc == 0); nothing is read back.
+ * ------------------------------------------------------------------ */
+typedef struct {
+  const float* extrinsics; const float* intrinsics; const int32_t* index;
+  int32_t B; int32_t S; int32_t Sc; int32_t H; int32_t W; int32_t G;
+  const float* pose_w; const float* pose_b;
+  const float* adapt_w; const float* adapt_b;
+  float* enc; float* emb; float* tables;
+} ovg_camera_tables_params;
+int ovg_camera_tables(const ovg_camera_tables_params*, void* stream);
 
 /* MFMA lane-map probe (diagnostics; tools/selftest.py): fills out[64*4] with
  * acc of one 16x16 MFMA for dtype given raw 16-byte A/B fragments per lane. */

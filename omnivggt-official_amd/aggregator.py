@@ -106,14 +106,17 @@ class Workspace:
         self.q, self.k, self.vt = ops.alloc_qkv(self.BH, rows, rows, dtype, device)
         self.device, self._split = device, {}
 
-    def split_ws(self, variant=0):
-        """(ws_part, ws_lse) for this shape's self-attention launch if ovg_attn_plan wants to split it along the keys
-        (launches that would leave CUs idle: 8-view global attention = 688 workgroups on 512 slots), else (None, None)."""
-        if variant not in self._split:
-            plan = (ops.attn_plan(self.BH, self.seq, [self.seq], self.dtype, variant, nq_pad=self.q.shape[1])
-                    if self.dtype != torch.float32 else {"splits": 1})
-            self._split[variant] = ops.alloc_split_ws(plan, self.device)
-        return self._split[variant]
+    def split_ws(self, variant=0, kv_splits=0):
+        """(ws_part, ws_lse) for this shape's self-attention launch if ovg_attn_plan -- asked with the SAME variant and the same
+        forced / automatic split factor the launch will carry -- cuts it along the keys (launches that would leave CUs idle:
+        8-view global attention = 688 workgroups on 512 slots), else (None, None). The buffers' sizes travel with the pointers
+        (ovg_attn_params.ws_part_bytes / ws_lse_bytes), so a plan / launch mismatch is an error code, not an overrun."""
+        key = (variant, kv_splits)
+        if key not in self._split:
+            plan = (ops.attn_plan(self.BH, self.seq, [self.seq], self.dtype, variant, kv_splits, nq_pad=self.q.shape[1])
+                    if (self.dtype != torch.float32 and kv_splits != 1) else {"splits": 1})
+            self._split[key] = ops.alloc_split_ws(plan, self.device)
+        return self._split[key]
 
     def share_from(self, other):
         """Reuse the LN / attention / hidden scratch of another workspace with the same M."""
@@ -176,8 +179,9 @@ class BlockRunner:
         p.gemm_tile = int(getattr(self.knobs, "gemm_tile", 0))
         p.attn_kv_splits = int(getattr(self.knobs, "attn_kv_splits", 0))
         if p.attn_kv_splits != 1 and hasattr(ws, "split_ws"):
-            part, lse = ws.split_ws(p.attn_variant)
+            part, lse = ws.split_ws(p.attn_variant, p.attn_kv_splits)
             p.ws_attn_part, p.ws_attn_lse = L.ptr(part), L.ptr(lse)
+            p.ws_attn_part_bytes, p.ws_attn_lse_bytes = ops.nbytes(part), ops.nbytes(lse)
         return p
 
     def forward(self, ws, x_in, x_out, inject=None, inj_period=0, events=None, **kw):
@@ -233,7 +237,6 @@ class ZeroAggregator(nn.Module):
             nn.init.zeros_(a.bias)
         self.depth_patch_embed = _ConvProj(2, embed_dim)
         self.pose_hidden_dim = pose_hidden_dim
-        self.pose_k_pad = (pose_hidden_dim + 63) // 64 * 64     # K of the stacked pose-embedding GEMM (ovg_linear: K % 64 == 0)
         self.compute_dtype = compute_dtype
         self.attn_variant = 0       # ovg_attn_params.variant of every attention call (0 = library default); read per call
         self.gemm_tile = 0          # OVG_TILE_* forced on the block GEMMs (tests); 0 = shape heuristic
@@ -335,6 +338,10 @@ class ZeroAggregator(nn.Module):
         dt = self.compute_dtype
         if sd is None:
             sd = {k: v for k, v in self.state_dict().items()}
+            if any(v.is_meta for v in sd.values()):
+                raise L.OvgError("this aggregator's parameters live on the meta device (OmniVGGT.from_packed keeps only the packed "
+                                 "weights): it can run its packed dtype on the device it was loaded to, but it cannot be re-packed "
+                                 "for another dtype / device -- load the original checkpoint (from_safetensors) for that")
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         rope = make_rope_tables(ROPE_MAX_POS, device, self.rope_freq)
         pk = {"device": device, "dtype": dt, "rope": rope}
@@ -358,15 +365,12 @@ class ZeroAggregator(nn.Module):
         pk["camera_token"] = f32(sd["camera_token"].reshape(2, C))
         pk["register_token"] = f32(sd["register_token"].reshape(2, -1, C))
         pk["placeholder"] = f32(sd["depth_placeholder"].reshape(-1))
-        # camera modality tables (exact f32 MFMA path): all pose embeddings stacked into one GEMM
+        # camera modality tables (ovg_camera_tables, exact f32): the 25 pose embeddings and the 25 adapters stacked
         G = self.depth + 1
-        pe_w = torch.zeros(G * C, self.pose_k_pad)
-        for i in range(G):
-            pe_w[i * C:(i + 1) * C, : self.pose_hidden_dim] = sd["pose_embeddings.%d.weight" % i].float().cpu()
-        pk["pose_w"] = pe_w.to(device)
-        pk["pose_b"] = torch.cat([sd["pose_embeddings.%d.bias" % i].float().cpu() for i in range(G)]).to(device)
-        pk["adapt_w"] = [f32(sd["camera_adapters.%d.weight" % i]) for i in range(G)]
-        pk["adapt_b"] = [f32(sd["camera_adapters.%d.bias" % i]) for i in range(G)]
+        pk["pose_w"] = torch.cat([sd["pose_embeddings.%d.weight" % i].detach().float().cpu() for i in range(G)]).contiguous().to(device)   # [G*1024, 9]
+        pk["pose_b"] = torch.cat([sd["pose_embeddings.%d.bias" % i].detach().float().cpu() for i in range(G)]).contiguous().to(device)
+        pk["adapt_w"] = torch.stack([f32(sd["camera_adapters.%d.weight" % i]) for i in range(G)]).contiguous()                              # [G,1024,1024]
+        pk["adapt_b"] = torch.stack([f32(sd["camera_adapters.%d.bias" % i]) for i in range(G)]).contiguous()                                # [G,1024]
         self._packed = pk
         return pk
 
@@ -414,33 +418,31 @@ class ZeroAggregator(nn.Module):
 
     # ------------------------------------------------------------------
     def camera_tables(self, pk, extrinsics, intrinsics, camera_gt_index, B, S, hw, device):
-        """[depth+1] list of f32 [B*S,1024]: camera_adapters[i](scatter(pose_embeddings[i](enc)))
-        (omnivggt_aggregator.py:158-182,211,273-287).  Views without a GT camera get the
-        adapter bias (Linear of a zero row)."""
+        """f32 [depth+1, B*S, 1024]: camera_adapters[i](scatter(pose_embeddings[i](enc)))
+        (omnivggt_aggregator.py:85-105,158-182,211,273-287). Views without a GT camera get the adapter bias (Linear of a
+        zero row). Built by ONE C call (ovg_camera_tables: selection, normalisation, pose encoding, the stacked Linear(9 -> 1024),
+        the 25 adapters as one batched exact-f32 GEMM over the camera rows, bias fill) from DEVICE extrinsics / intrinsics:
+        no device -> host copy, no sync, <= 3 launches per forward. camera_math.py keeps the same arithmetic as host-side
+        PyTorch (used by the post-processing helpers and as this entry's test twin)."""
         K = B * S
-        G = self.depth + 1
         if len(camera_gt_index) == 0:
             key = ("bias_tables", K)
             if key not in pk:               # Linear(0) = bias for every view; constant across calls
-                pk[key] = [b.unsqueeze(0).expand(K, C).contiguous() for b in pk["adapt_b"]]
+                pk[key] = ops.camera_tables(None, None, None, K, hw, pk["pose_w"], pk["pose_b"], pk["adapt_w"], pk["adapt_b"])
             return pk[key]
-        idx = torch.tensor(list(camera_gt_index))
-        ext = torch.index_select(extrinsics.detach().float().cpu(), 1, idx)
-        intr = torch.index_select(intrinsics.detach().float().cpu(), 1, idx)
-        enc = camera_math.pose_encoding(camera_math.normalize_extrinsics(ext), intr, hw)      # [B,Sc,9]
-        Sc = len(camera_gt_index)
-        x = torch.zeros(B * Sc, self.pose_k_pad)
-        x[:, : self.pose_hidden_dim] = enc.reshape(B * Sc, -1)
-        emb = ops.linear(x.to(device), pk["pose_w"], pk["pose_b"], torch.float32, out_f32=True)   # [B*Sc, G*1024]
-        rows = (torch.arange(B).unsqueeze(1) * S + idx.unsqueeze(0)).reshape(-1).to(device)
-        # only the camera views go through the adapters (same kernel, same k order as a full [K,1024] GEMM would use for
-        # those rows); every other row is Linear(0) = bias exactly.  One table buffer, one scatter.
-        tables = torch.stack(pk["adapt_b"]).unsqueeze(1).repeat(1, K, 1)                          # [G,K,1024]
-        out = torch.empty(G, B * Sc, C, device=device)
-        for i in range(G):
-            ops.linear(emb[:, i * C:(i + 1) * C], pk["adapt_w"][i], pk["adapt_b"][i], torch.float32, out=out[i], out_f32=True)
-        tables[:, rows] = out
-        return list(tables.unbind(0))
+        if self.pose_hidden_dim != 9:
+            raise ValueError("ovg_camera_tables encodes cameras as absT_quaR_FoV (9 values); pose_hidden_dim=%d" % self.pose_hidden_dim)
+        idx_key = ("cam_index", tuple(int(i) for i in camera_gt_index))
+        if idx_key not in pk:               # the index list reaches the device once per distinct list, not once per forward
+            if min(idx_key[1]) < 0 or max(idx_key[1]) >= S:
+                raise IndexError("camera_gt_index out of range for %d views" % S)
+            cached = [k for k in pk if isinstance(k, tuple) and k and k[0] == "cam_index"]
+            if len(cached) >= 16:           # a long-lived process with ever-changing index lists: start over
+                for k in cached:
+                    del pk[k]
+            pk[idx_key] = torch.tensor(idx_key[1], dtype=torch.int32).to(device)
+        return ops.camera_tables(extrinsics.to(device), intrinsics.to(device), pk[idx_key], S, hw,
+                                 pk["pose_w"], pk["pose_b"], pk["adapt_w"], pk["adapt_b"])
 
     def depth_tokens(self, pk, depth, mask, depth_gt_index, B, S, device):
         """(depth_tok [B*n*P0,1024] f32 or None, depth_row int32 [B*S])

@@ -11,9 +11,9 @@
 // running max/sum/alpha are lane-local, and P feeds the PV MFMA with NO cross-lane
 // movement: the k-slot -> key assignment of the P fragment is simply mirrored by the
 // V^T fragment gather (two 8-byte LDS reads per fragment for 16-bit types).
-// V arrives pre-transposed (V^T [BH,64,nk_pad], written by the QKV epilogue; 16-bit rows in the vt_pos16 key order), K/V^T tiles
-// are register-staged into double-buffered LDS (issue-early / write-late), the K tile is
-// XOR-swizzled and the V^T tile row-padded so every fragment read is conflict free.
+// V arrives pre-transposed (V^T [BH,64,nk_pad], written by the QKV epilogue; 16-bit rows in the vt_pos16 key order). This file holds
+// the baseline kernel (f32 parity mode + A/B reference: K/V^T tiles register-staged into LDS, issue-early / write-late, K tile
+// XOR-swizzled, V^T tile row-padded) and the launch plan; the tuned 16-bit kernels (LDS-DMA staged) are in ovg_attn16.h.
 // q is pre-scaled by softmax_scale*log2(e): probabilities are exp2(s - m).
 // K/V^T may come as several segments (one per rank of the view-sharded all-gather).
 #include "ovg_common.h"
@@ -272,9 +272,10 @@ int launch_attn(const ovg_attn_params& p, hipStream_t st) {
 // ---- launch plan of the 16-bit kernels: q tile (256 or 512 rows) and split-KV factor ---------------------------------
 // `slots` = workgroups resident at once (256 CUs x 2 workgroups of 4 waves, or x 1 of 8 waves). A launch of U equal units
 // takes ceil(U / slots) rounds; cutting every unit into s key ranges makes the rounds 1/s as long at ~1.5 key tiles of
-// fixed cost per unit (anchor prologue, Q load, epilogue). The default q tile is 256 rows; launches of >= 8 full rounds of
-// 512-row tiles take those (1 workgroup of 8 waves per CU: every staged K / V^T tile feeds twice the rows; +2.2 % at
-// 64 views, -17 % at 8 views -- profiles/r02_attention_variants_ab.txt).
+// fixed cost per unit (anchor prologue, Q load, epilogue). The default q tile is 256 rows; launches of >= 2.5 rounds of
+// 512-row tiles take those (1 workgroup of 8 waves per CU: every staged K / V^T tile feeds twice the rows; 16 views +5.9 %,
+// 64 views +3 %, 8 views -17 % -- profiles/r02_attention_dma_ab.txt), with the rows beyond the last full round in a second
+// launch of 128-row tiles (dispatch16).
 struct Plan16 { int variant; int bq; int splits; int per_split; int total_tiles; };
 
 int cu_count_attn() {
@@ -296,6 +297,7 @@ Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
   Plan16 pl{};
   int v = p.variant;
   if (v == 71) v = 57;            // A/B tool: the 512-row kernel with its tail split (dispatch16)
+  if (v == 72) v = 50;            // A/B tool: the 256-row kernel with a tail split (dispatch16)
   const int cus = cu_count_attn();
   const int64_t units512 = p.BH * ((p.nq + 511) / 512);
   // 512-row tiles (8 waves, one workgroup per CU, barrier every 2 tiles) from ~2.5 rounds of them on: 16 views +5.9 %, 64 views +3 %
@@ -381,7 +383,11 @@ template <typename T>
 int dispatch16(const ovg_attn_params& p, hipStream_t st) {
   constexpr bool kBf16 = std::is_same<T, bf16_t>::value;
   const Plan16 pl = plan16(p, kBf16, p.ws_part != nullptr && p.ws_lse != nullptr);
-  if (pl.splits > 1 && (p.ws_part == nullptr || p.ws_lse == nullptr)) return OVG_E_ARG;
+  if (pl.splits > 1) {   // the partials go to caller memory: refuse a missing or undersized workspace instead of writing past it
+    if (p.ws_part == nullptr || p.ws_lse == nullptr) return OVG_E_ARG;
+    const int64_t rows = (int64_t)pl.splits * p.BH * p.nq_pad;
+    if (p.ws_part_bytes < rows * OVG_D * 2 || p.ws_lse_bytes < rows * 4) return OVG_E_ARG;
+  }
   // Tail split of the 512-row kernel (automatic plan; variant 71 forces it for the A/B tool): a launch of R = units / 256 rounds pays
   // a whole round -- or more: one workgroup per CU, nothing to overlap with -- for its fractional last one (tools/probes/attn_tail_probe.py,
   // 64 views: 22.18 ms for 10.0 rounds, 24.91 ms for 10.75: +4.6 % per row). The full rounds keep the 512-row tiles; the remaining rows of
@@ -396,6 +402,20 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
     const int64_t rows_a = full * slots / p.BH * pl.bq;
     if (full >= 2 && frac > 0.05 && frac < 0.85 && rows_a > 0 && rows_a < p.nq) {
       const int rc = launch_attn16<T, 4, 8, 0, 2, false, 5>(p, pl, st, 0, rows_a);
+      return rc != OVG_OK ? rc : launch_attn16<T, 2, 4, 0, 2, false, 3>(p, pl, st, rows_a, p.nq);
+    }
+  }
+  // The same split for the 256-row kernel (two workgroups per CU) in the 1 .. 2.5-round regime -- 8 to 14 views on one GPU: 688 workgroups
+  // on 512 slots at 8 views leave the second "round" a third full, one workgroup per CU on 176 CUs. The first full round(s) keep the 256-row
+  // tiles, the remaining rows of every head go to 128-row tiles (three per CU) over the whole chip.
+  if ((p.variant == 0 || p.variant == 72) && pl.splits == 1 && pl.variant == 50 && p.nq >= 4096) {
+    const int slots = 2 * cu_count_attn();
+    const int64_t units = p.BH * ((p.nq + pl.bq - 1) / pl.bq);
+    const int64_t full = units / slots;
+    const double frac = (double)units / slots - (double)full;
+    const int64_t rows_a = full * slots / p.BH * pl.bq;
+    if (full >= 1 && frac > 0.05 && frac < 0.85 && rows_a > 0 && rows_a < p.nq) {
+      const int rc = launch_attn16<T, 4, 4, 0, 2, false, 3>(p, pl, st, 0, rows_a);
       return rc != OVG_OK ? rc : launch_attn16<T, 2, 4, 0, 2, false, 3>(p, pl, st, rows_a, p.nq);
     }
   }

@@ -8,8 +8,10 @@
 //    operand accumulates sum_k P (PMC on the previous kernel: VALU-active 52 % vs MFMA-busy 33 %);
 //  * __launch_bounds__(NT, 2): <= 256 VGPRs, VGPR-destination MFMAs (no v_accvgpr traffic); the file is
 //    compiled with -fno-honor-nans (no canonicalising v_max before fmaxf of MFMA results);
-//  * K / V^T tiles (64 keys) register-staged into double-buffered LDS: global loads of tile j+1 are issued
-//    before the MFMAs of tile j and written to the other buffer after them; one barrier per tile.
+//  * K / V^T tiles (64 keys) arrive by LDS-DMA (DMA = R > 0, every shipped launch): asm-issued global_load_lds_dwordx4
+//    into a ring of R = 2 B + 1 LDS slots, B + 1 tiles ahead, behind counted vmcnt waits, one workgroup barrier every
+//    B tiles (run_tiles below). DMA = 0 keeps the round-1 register-staged form (global loads of tile j+1 issued before
+//    the MFMAs of tile j, written to the other of two buffers after them, one barrier per tile) as A/B variants.
 //
 // Two softmax bodies share that structure (run_tiles<..., SM>):
 //  SM = 0  lazy-rescale online softmax: m_ref moves only when a row's tile max exceeds it by more than
@@ -100,17 +102,7 @@ OVG_DEV u32x4 pack2(const f32x4 a, const f32x4 b) {
 // One pass over all key tiles of all segments for the wave's QB x 16 query rows; leaves the un-normalised
 // O^T in o, the row sums in lacc (every register of lacc[qb] holds the full sum of row q0 + 16 qb + lane&15) and the
 // negated reference maximum in negm (P = exp2(s + negm)): log2 sum_k exp2(s) = log2(lacc) - negm.
-// LDS-DMA of one 16-byte granule per lane: lane l of the wave lands at lds_dst + 16 l (lds_dst wave-uniform, in M0).
-// Inline asm on purpose: hipcc treats the builtin form as a FLAT access that may touch LDS ("pending flat"), after which
-// EVERY s_waitcnt it generates in the loop becomes vmcnt(0) / lgkmcnt(0) -- the prefetch is drained where it was issued and
-// the ds_read pipelining of the tile body is lost. Opaque to the compiler, the transfers are covered by the explicit counted
-// s_waitcnt vmcnt in run_tiles.
-OVG_DEV void lds_dma16(const void* gsrc, uint32_t lds_dst) {
-  // M0 is written without being declared (it is a reserved register: hipcc rejects it as a clobber); hipcc itself never keeps a
-  // value live in M0 on gfx9+ -- it materialises M0 immediately in front of each of its own uses (LDS-DMA builtin, s_sendmsg).
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_dst), "v"(gsrc) : "memory");
-}
-
+// (lds_dma16, the asm-issued LDS-DMA transfer the staging below uses, lives in ovg_common.h)
 template <typename T, int QB, int WAVES, int SM, bool VSUM = false, int DMA = 0>   // VSUM: row sums on the VALU (experiment, variant 31) instead of the ones-MFMA; DMA: 0 = register staging, R = 2 B + 1 (3, 5, 7, 9): K / V^T tiles by LDS-DMA into a ring of R slots, B + 1 tiles ahead, one workgroup barrier every B tiles
 OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int bh, const int q0, const int t_begin, const int total_tiles,
                        f32x4 (&o)[QB][4], f32x4 (&lacc)[QB], f32x4 (&negm)[QB]) {   // key tiles [t_begin, t_begin + total_tiles) of the flattened segment list

@@ -132,6 +132,17 @@ OVG_DEV int xcd_remap(int b, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// LDS-DMA of one 16-byte granule per lane: lane l of the wave lands at lds_dst + 16 l (lds_dst wave-uniform, in M0).
+// Inline asm on purpose: hipcc treats the builtin form as a FLAT access that may touch LDS ("pending flat"), after which
+// EVERY s_waitcnt it generates nearby becomes vmcnt(0) / lgkmcnt(0) -- the prefetch is drained where it was issued and the
+// ds_read pipelining around it is lost. Opaque to the compiler, the transfers are covered by explicit counted s_waitcnt vmcnt
+// at the use sites (attention: run_tiles in ovg_attn16.h; GEMM: the residual epilogue of the 256 x 256 kernels).
+OVG_DEV void lds_dma16(const void* gsrc, uint32_t lds_dst) {
+  // M0 is written without being declared (it is a reserved register: hipcc rejects it as a clobber); hipcc itself never keeps a
+  // value live in M0 on gfx9+ -- it materialises M0 immediately in front of each of its own uses (LDS-DMA builtin, s_sendmsg).
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_dst), "v"(gsrc) : "memory");
+}
+
 // hipGetLastError() is per-thread and sticky until read: the host framework's own benign failures
 // (hipEventQuery -> NotReady, hipPointerGetAttributes on pageable memory, ...) must not be mistaken
 // for a failed launch of ours, so the slot is drained immediately before every launch.

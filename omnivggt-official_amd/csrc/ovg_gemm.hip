@@ -14,6 +14,10 @@
 // residual / output accesses are 16-byte vectors.  LDS tiles are XOR-swizzled
 // (ovg_common.h: swz_off) so the ds_read_b128 fragment reads are conflict free.
 #include "ovg_common.h"
+#include <mutex>
+#include <type_traits>
+#include <utility>
+#include <vector>
 
 namespace {
 
@@ -35,6 +39,35 @@ OVG_DEV float erf_as(float x) {
 template <typename T> OVG_DEV float gelu_erf(float x) {
   if constexpr (sizeof(T) == 4) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
   else return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
+}
+// Transcendental-free form for the 16-bit modes (r03): GELU(x) = x * Phi(x), Phi(x) = 1/2 + xc * R(xc^2), xc = clamp(x, -5, 5),
+// R a degree-12 minimax polynomial in u = 2 xc^2 / 25 - 1 (fitted against erf in double; evaluated in f32 Horner form the
+// error of GELU is <= 2.2e-6 absolute for |x| <= 12 and <= 3e-7 |x| beyond: two decimal orders below bf16 / f16 resolution,
+// the same class as erf_as). 17 plain VALU operations, 16 of them FMA / MUL that hipcc pairs into v_pk_fma_f32 / v_pk_mul_f32
+// across neighbouring elements, no v_rcp / v_exp and none of the ~2 s_nop per element their result hazards cost
+// (ISA of the fc1 epilogue: 13.5 -> 9 issue slots per element).
+// One row block of a lane (16 values) at a time, Horner step by Horner step ACROSS the 8 register pairs: a v_pk_fma_f32 that
+// consumes the previous packed result back-to-back costs an s_nop each (hipcc, evaluating chain after chain, emitted 652 s_nop for
+// 896 v_pk_fma_f32); eight independent chains in flight need none.
+OVG_DEV void gelu_poly16(f32x4 (&v)[4]) {
+  constexpr float c[13] = {1.413637876e-01f, -7.029628064e-02f, 5.152052248e-02f, -4.044260701e-02f, 3.144217031e-02f, -2.326865498e-02f,
+                           1.640218381e-02f, -1.116433345e-02f, 6.410491046e-03f, -2.685581490e-03f, 1.722817794e-03f, -1.613262584e-03f,
+                           6.087207876e-04f};
+  f32x4 xc[4], u[4], r[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xc[nt][i] = __builtin_amdgcn_fmed3f(v[nt][i], -5.0f, 5.0f);
+    u[nt] = xc[nt] * xc[nt] * 0.08f - 1.0f;
+    r[nt] = u[nt] * c[12] + c[11];
+  }
+#pragma unroll
+  for (int k = 10; k >= 0; --k) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) r[nt] = r[nt] * u[nt] + c[k];
+  }
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) v[nt] = v[nt] * (xc[nt] * r[nt] + 0.5f);
 }
 
 // Logical block id -> (m tile, n tile), "grouped" order: GM m-tiles x all n-tiles at a time, m fastest.
@@ -149,7 +182,7 @@ OVG_DEV void gemm_mainloop(const T* __restrict__ X, int64_t ldx, const T* __rest
 // Now: the per-column vectors (bias, gamma) are loaded ONCE per wave, the row loop bodies are branch-free (row
 // indices clamped for the loads, only the store is predicated), so the four residual / table loads of a row block
 // -- and, registers permitting, the next row block's -- are in flight together.
-template <typename T, int EPI, bool OUT_F32, int MT, bool INJECT>
+template <typename T, int EPI, bool OUT_F32, int MT, bool INJECT, int XP = 0>   // XP = 1: r03 epilogue forms (OVG_TILE_256X): polynomial GELU (the residual form of XP is res_epilogue_dma)
 OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int n_w0) {
   const int M = (int)p.M, N = (int)p.N;
   const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
@@ -166,63 +199,89 @@ OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) gam[nt] = *reinterpret_cast<const f32x4*>(p.gamma + ncol + nt * 16);
   }
-  // row-block operands (residual / position-table rows, injection rows) are fetched ONE ROW BLOCK AHEAD by hand: the
+  // row-block operands (residual / position-table rows, injection rows) are fetched AH ROW BLOCKS AHEAD by hand: the
   // output may alias the residual (fc2 runs in place), so the compiler may not move a later block's loads above an
   // earlier block's stores on its own; different row blocks never touch the same rows, so doing it by hand is safe.
+  // AH: 0 in the 128 x 128 kernels (3 workgroups per CU hide the latency and must stay <= 168 VGPRs), 1 in the 256 x 256
+  // kernels (1 workgroup per CU: nobody else hides it). A deeper register ring does not fit beside the 128 accumulators
+  // (AH = 3 spilled 380 bytes): the residual epilogue of full tiles goes through LDS-DMA instead (res_epilogue_dma below).
   constexpr bool kRowLoads = (EPI == OVG_EPI_RES || EPI == OVG_EPI_PATCH);
-  // one-ahead prefetch only in the 256 x 256 kernels (1 workgroup per CU: nobody else hides the latency); the 128 x 128
-  // kernels run 3 workgroups per CU at <= 168 VGPRs and must not grow past that
-  constexpr bool kAhead = kRowLoads && MT == 8;
+  constexpr int AH = !kRowLoads ? 0 : (MT == 8 ? 1 : 0);
+  constexpr int NS = AH + 1;                            // ring slots; every index below is a compile-time constant after unrolling
   const FastDiv div_p0(EPI == OVG_EPI_PATCH ? (int)p.p0 : 1), div_per(INJECT ? (int)p.inj_period : 1);
-  f32x4 ex_cur[4], ex_nxt[4], inj_cur[4], inj_nxt[4];
-  float on_cur = 0.f, on_nxt = 0.f;
-  int64_t orow_cur = 0, orow_nxt = 0;
-  auto fetch = [&](int mt, f32x4 (&ex)[4], f32x4 (&inj)[4], float& on, int64_t& orow) {
+  f32x4 ex[NS][4], inj[NS][4];
+  float on[NS];
+  int64_t orow_s[NS];
+  auto fetch = [&](int mt, f32x4 (&exs)[4], f32x4 (&injs)[4], float& ons, int64_t& orow) {
     const int m = m_w0 + mt * 16 + lr;
     const int mc = m < M ? m : M - 1;                  // loads of dead rows read a live row instead of branching
     orow = mc;
+    ons = 0.f;
     if constexpr (EPI == OVG_EPI_PATCH) {
       int vw, t;
       div_p0.divmod(mc, vw, t);
       orow = (int64_t)vw * p.p1 + p.row_off + t;
       const float* trow = p.table + (int64_t)(t + 1) * N + ncol;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) ex[nt] = *reinterpret_cast<const f32x4*>(trow + nt * 16);
+      for (int nt = 0; nt < 4; ++nt) exs[nt] = *reinterpret_cast<const f32x4*>(trow + nt * 16);
     }
     if constexpr (EPI == OVG_EPI_RES) {
       const float* rrow = p.res + (int64_t)mc * p.ldres + ncol;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) ex[nt] = *reinterpret_cast<const f32x4*>(rrow + nt * 16);
+      for (int nt = 0; nt < 4; ++nt) exs[nt] = *reinterpret_cast<const f32x4*>(rrow + nt * 16);
       if constexpr (INJECT) {
         // camera-token injection (omnivggt_aggregator.py:284-301) on rows m % period == 0: every lane reads ITS view's
         // row (an L1 / L2 hit: 1 row per 1374) and scales it by 0 or 1 -- no divergent branch in the row loop
         int vw, rem;
         div_per.divmod(mc, vw, rem);
-        on = rem == 0 ? 1.0f : 0.0f;
+        ons = rem == 0 ? 1.0f : 0.0f;
         const float* irow = p.inject + (int64_t)vw * N + ncol;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) inj[nt] = *reinterpret_cast<const f32x4*>(irow + nt * 16);
+        for (int nt = 0; nt < 4; ++nt) injs[nt] = *reinterpret_cast<const f32x4*>(irow + nt * 16);
       }
     }
   };
-  if (kAhead) fetch(0, ex_cur, inj_cur, on_cur, orow_cur);
+  if constexpr (kRowLoads) {
+#pragma unroll
+    for (int a = 0; a < AH; ++a) fetch(a, ex[a], inj[a], on[a], orow_s[a]);
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    if (kAhead) { if (mt + 1 < MT) fetch(mt + 1, ex_nxt, inj_nxt, on_nxt, orow_nxt); }
-    else if (kRowLoads) fetch(mt, ex_cur, inj_cur, on_cur, orow_cur);
+    if constexpr (kRowLoads) {
+      if (mt + AH < MT) fetch(mt + AH, ex[(mt + AH) % NS], inj[(mt + AH) % NS], on[(mt + AH) % NS], orow_s[(mt + AH) % NS]);
+    }
+    const int cs = mt % NS;                             // slot of this row block
     const bool ok = (m_w0 + mt * 16 + lr) < M;
     f32x4 v[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       v[nt] = acc[nt][mt] + bias[nt];
       if constexpr (EPI == OVG_EPI_GELU) {
-        v[nt][0] = gelu_erf<T>(v[nt][0]); v[nt][1] = gelu_erf<T>(v[nt][1]); v[nt][2] = gelu_erf<T>(v[nt][2]); v[nt][3] = gelu_erf<T>(v[nt][3]);
+        if constexpr (!(XP && sizeof(T) == 2)) {     // the XP form handles the four column blocks of the row block together, below
+          v[nt][0] = gelu_erf<T>(v[nt][0]); v[nt][1] = gelu_erf<T>(v[nt][1]); v[nt][2] = gelu_erf<T>(v[nt][2]); v[nt][3] = gelu_erf<T>(v[nt][3]);
+        }
+        if constexpr (std::is_same<T, f16_t>::value && !(XP && sizeof(T) == 2)) {
+          // f16 range guard: the hidden activation is the one 16-bit tensor fed by an unnormalised f32 sum (DINOv2-style
+          // massive activations reach 1e3..1e4 after fc1); saturate at the largest finite f16 instead of storing +inf
+          // (inf * 0-weight = NaN in fc2). GELU is bounded below by -0.17, so only the upper side needs it.
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[nt][r] = fminf(v[nt][r], 65504.0f);
+        }
       }
-      if constexpr (EPI == OVG_EPI_RES) v[nt] = ex_cur[nt] + gam[nt] * v[nt];
-      if constexpr (EPI == OVG_EPI_RES && INJECT) v[nt] += on_cur * inj_cur[nt];
-      if constexpr (EPI == OVG_EPI_PATCH) v[nt] += ex_cur[nt];
+      if constexpr (EPI == OVG_EPI_RES) v[nt] = ex[cs][nt] + gam[nt] * v[nt];
+      if constexpr (EPI == OVG_EPI_RES && INJECT) v[nt] += on[cs] * inj[cs][nt];
+      if constexpr (EPI == OVG_EPI_PATCH) v[nt] += ex[cs][nt];
     }
-    const int64_t orow = kRowLoads ? orow_cur : (int64_t)(m_w0 + mt * 16 + lr);
+    if constexpr (EPI == OVG_EPI_GELU && XP && sizeof(T) == 2) {
+      gelu_poly16(v);
+      if constexpr (std::is_same<T, f16_t>::value) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[nt][r] = fminf(v[nt][r], 65504.0f);
+      }
+    }
+    const int64_t orow = kRowLoads ? orow_s[cs] : (int64_t)(m_w0 + mt * 16 + lr);
     if (ok) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
@@ -233,20 +292,90 @@ OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)
         }
       }
     }
-    if (kAhead && mt + 1 < MT) {
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) { ex_cur[nt] = ex_nxt[nt]; inj_cur[nt] = inj_nxt[nt]; }
-      on_cur = on_nxt; orow_cur = orow_nxt;
-    }
   }
 }
 
-template <typename T, int EPI, bool OUT_F32, int MT>
+// Residual epilogue of the 256 x 256 kernels with the residual tile fetched by LDS-DMA (XP form, no injection, full tiles):
+//   y[m, n] = res[m, n] + gamma[n] * (acc + bias[n])          (attention.py:75 / mlp.py:38 + layer_scale.py:27 + block.py:105-106)
+// The register-prefetch form above keeps ONE row block (4 x 16 B per lane) of residual in flight per wave and pays a memory round
+// trip per row block: 8 exposed round trips per wave, 23 us of proj's 50 us tile (profiles/r02_gemm_epilogue_mlp.txt). More
+// registers are not available (128 accumulators + bias + gamma). After the main loop, however, the 128 KB LDS ring is idle:
+// every wave owns 16 KB of it = FOUR row blocks of its 64 x 128 f32 block. All four are requested at once (16 LDS-DMA
+// instructions, no registers), a row block is consumed as soon as ITS four transfers have landed (counted vmcnt: in-order
+// retirement; the y stores count too on CDNA4 and are in the arithmetic below), and its slot is refilled with row block + 4
+// straight away -- 12-16 KB per wave in flight throughout instead of 4 KB.
+//   LDS image: instruction (slot, nt) -> 1 KB at wave_base + (slot * 4 + nt) * 1024, lane l at + 16 l: exactly the 16 bytes lane l
+//   needs for (row lr = l & 15, columns ncol + 16 nt .. + 3), so the read-back is one lane-linear (conflict-free) ds_read_b128.
+//   VMEM ops after group G_j (4 DMAs of row block j) when iteration j waits for it, S_i = the 4 stores of iteration i:
+//     j = 0: G1 G2 G3                          -> vmcnt(12)      j = 4: S1 G5 S2 G6 S3 G7      -> vmcnt(24)
+//     j = 1: G2 G3 S0 G4                       -> vmcnt(16)      j = 5: S2 G6 S3 G7 S4         -> vmcnt(20)
+//     j = 2: G3 S0 G4 S1 G5                    -> vmcnt(20)      j = 6: S3 G7 S4 S5            -> vmcnt(16)
+//     j = 3: S0 G4 S1 G5 S2 G6                 -> vmcnt(24)      j = 7: S4 S5 S6               -> vmcnt(12)
+//   WAR on a slot: the refill of slot j % 4 is issued after the ds_reads of row block j have RETURNED (s_waitcnt lgkmcnt(0)).
+// Only for tiles whose 128 rows are all live (the stores are then unconditional: the counts above are exact); the ragged last
+// m-tile and the injection variant (its table loads are compiler-visible VMEM ops whose waits would drain the DMA queue) take
+// the register form.
+template <typename T>
+OVG_DEV void res_epilogue_dma(const ovg_linear_params& p, const f32x4 (&acc)[4][8], const int m_w0, const int n_w0, unsigned char* lds) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ncol = n_w0 + 4 * g;
+  f32x4 bias[4], gam[4];
+  if (p.bias != nullptr) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bias[nt] = *reinterpret_cast<const f32x4*>(p.bias + ncol + nt * 16);
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bias[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) gam[nt] = *reinterpret_cast<const f32x4*>(p.gamma + ncol + nt * 16);
+  // fold gamma * bias now: this USES the two vectors, so the compiler's wait for their loads sits here, in front of the first
+  // DMA, not in front of the first row block (where its vmcnt(0) would drain the sixteen transfers just issued)
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) bias[nt] = gam[nt] * bias[nt];
+  asm volatile("" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3]), "+v"(gam[0]), "+v"(gam[1]), "+v"(gam[2]), "+v"(gam[3]));
+
+  const uint32_t wbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds) + (uint32_t)wave * 16384u;
+  const float* rlane = p.res + (int64_t)(m_w0 + lr) * p.ldres + ncol;        // this lane's 16 bytes of row block 0, column block 0
+  float* ylane = static_cast<float*>(p.y) + (int64_t)(m_w0 + lr) * p.ldy + ncol;
+  const unsigned char* lread = lds + wave * 16384 + lane * 16;
+  auto issue = [&](int mt) {
+    const float* src = rlane + (int64_t)mt * 16 * p.ldres;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) lds_dma16(src + nt * 16, wbase + (uint32_t)(((mt & 3) * 4 + nt) * 1024));
+  };
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) issue(mt);
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    // counted wait for group mt (table above)
+    if (mt == 0 || mt == 7) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (mt == 1 || mt == 6) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (mt == 2 || mt == 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    f32x4 ex[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) ex[nt] = *reinterpret_cast<const f32x4*>(lread + ((mt & 3) * 4 + nt) * 1024);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the reads have returned: the slot may be refilled
+    __builtin_amdgcn_sched_barrier(0);
+    float* yrow = ylane + (int64_t)mt * 16 * p.ldy;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const f32x4 v = ex[nt] + (gam[nt] * acc[nt][mt] + bias[nt]);
+      *reinterpret_cast<f32x4*>(yrow + nt * 16) = v;
+    }
+    __builtin_amdgcn_sched_barrier(0);                          // the 4 stores stay in front of the refill (the counts assume it)
+    if (mt + 4 < 8) issue(mt + 4);
+  }
+}
+
+template <typename T, int EPI, bool OUT_F32, int MT, int XP = 0>
 OVG_DEV void linear_epilogue(const ovg_linear_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int n_w0) {
   if constexpr (EPI == OVG_EPI_RES) {
-    if (p.inject != nullptr) { linear_epilogue_impl<T, EPI, OUT_F32, MT, true>(p, acc, m_w0, n_w0); return; }
+    if (p.inject != nullptr) { linear_epilogue_impl<T, EPI, OUT_F32, MT, true, XP>(p, acc, m_w0, n_w0); return; }
   }
-  linear_epilogue_impl<T, EPI, OUT_F32, MT, false>(p, acc, m_w0, n_w0);
+  linear_epilogue_impl<T, EPI, OUT_F32, MT, false, XP>(p, acc, m_w0, n_w0);
 }
 
 template <typename T, int EPI, bool OUT_F32>
@@ -483,7 +612,7 @@ __global__ __launch_bounds__(256, 3) void qkv_kernel(ovg_qkv_params p, int nt_be
 #include "ovg_gemm256.h"
 
 // 256 x 256 ping-pong variants (16-bit modes): same epilogues on acc[4][8]
-template <typename T, int EPI, bool OUT_F32>
+template <typename T, int EPI, bool OUT_F32, int XP = 0>
 __global__ __launch_bounds__(512) void linear256_kernel(ovg_linear_params p, int ntiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds256[];
   const int M = (int)p.M, N = (int)p.N, K = (int)p.K;
@@ -493,7 +622,12 @@ __global__ __launch_bounds__(512) void linear256_kernel(ovg_linear_params p, int
   f32x4 acc[4][8];
   g256::mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds256, acc);
   const int wave = threadIdx.x >> 6;
-  linear_epilogue<T, EPI, OUT_F32, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64);
+  const int m_w0 = m0 + (wave >> 2) * 128, n_w0 = n0 + (wave & 3) * 64;
+  if constexpr (EPI == OVG_EPI_RES && XP) {
+    // wave-uniform choice: all 128 rows of the wave live and no injection table -> residual by LDS-DMA through the idle ring
+    if (p.inject == nullptr && m_w0 + 128 <= M) { res_epilogue_dma<T>(p, acc, m_w0, n_w0, lds256); return; }
+  }
+  linear_epilogue<T, EPI, OUT_F32, 8, XP>(p, acc, m_w0, n_w0);
 }
 
 template <typename T>
@@ -517,9 +651,22 @@ __global__ __launch_bounds__(512) void qkv256_kernel(ovg_qkv_params p, int nt_be
   }
 }
 
+// Opt a kernel in to > 64 KB of dynamic LDS. The attribute is PER DEVICE, so it is set once per (kernel, device) -- a process
+// that drives a second GPU must not inherit the first one's "already done" (round-2 review: function-local statics did that).
+// The only state is this idempotent memo of calls already made.
 template <typename KernelT>
-int allow_big_lds(KernelT kernel, int bytes = g256::LDS_BYTES) {     // once per kernel: opt in to > 64 KB of dynamic LDS
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? OVG_OK : OVG_E_LAUNCH;
+int allow_big_lds(KernelT kernel, int bytes = g256::LDS_BYTES) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> done;
+  const void* fn = reinterpret_cast<const void*>(kernel);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return OVG_E_LAUNCH;
+  std::lock_guard<std::mutex> lock(mu);
+  for (const auto& d : done)
+    if (d.first == fn && d.second == dev) return OVG_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return OVG_E_LAUNCH;
+  done.emplace_back(fn, dev);
+  return OVG_OK;
 }
 
 // tile-order group sizes (m-tiles per group, tile_coords): measured in profiles/r01_gemm_tile_order_ab.txt / r01_gemm256_ab.txt
@@ -551,22 +698,22 @@ int launch_linear128(const ovg_linear_params& p, hipStream_t st) {
   OVG_CHECK_LAUNCH();
   return OVG_OK;
 }
-template <typename T, int EPI, bool OUT_F32>
+template <typename T, int EPI, bool OUT_F32, int XP = 0>
 int launch_linear256_one(const ovg_linear_params& p, hipStream_t st) {
-  static const int ok = allow_big_lds(linear256_kernel<T, EPI, OUT_F32>);
+  const int ok = allow_big_lds(linear256_kernel<T, EPI, OUT_F32, XP>);
   if (ok != OVG_OK) return ok;
   const int mt = (int)((p.M + g256::BM2 - 1) / g256::BM2), nt = (int)(p.N / g256::BN2);
   const int ntg = nt | (TILE_GROUP256 << 16);
-  OVG_LAUNCH((linear256_kernel<T, EPI, OUT_F32>), dim3(mt * nt), dim3(512), g256::LDS_BYTES, st, p, ntg);
+  OVG_LAUNCH((linear256_kernel<T, EPI, OUT_F32, XP>), dim3(mt * nt), dim3(512), g256::LDS_BYTES, st, p, ntg);
   OVG_CHECK_LAUNCH();
   return OVG_OK;
 }
 template <typename T>
-int launch_linear256(const ovg_linear_params& p, hipStream_t st) {
+int launch_linear256(const ovg_linear_params& p, hipStream_t st, bool xp) {
   switch (p.epilogue) {
     case OVG_EPI_STORE: return p.out_f32 ? launch_linear256_one<T, OVG_EPI_STORE, true>(p, st) : launch_linear256_one<T, OVG_EPI_STORE, false>(p, st);
-    case OVG_EPI_GELU: return launch_linear256_one<T, OVG_EPI_GELU, false>(p, st);
-    case OVG_EPI_RES: return launch_linear256_one<T, OVG_EPI_RES, true>(p, st);
+    case OVG_EPI_GELU: return xp ? launch_linear256_one<T, OVG_EPI_GELU, false, 1>(p, st) : launch_linear256_one<T, OVG_EPI_GELU, false>(p, st);
+    case OVG_EPI_RES: return xp ? launch_linear256_one<T, OVG_EPI_RES, true, 1>(p, st) : launch_linear256_one<T, OVG_EPI_RES, true>(p, st);
     case OVG_EPI_PATCH: return launch_linear256_one<T, OVG_EPI_PATCH, true>(p, st);
     default: return OVG_E_ARG;
   }
@@ -585,7 +732,7 @@ int launch_linear256(const ovg_linear_params& p, hipStream_t st) {
 int choose_256(int tile, bool sixteen_bit, int64_t M, int64_t N, int64_t K, bool light_epilogue_or_long_k) {
   const bool legal = sixteen_bit && N % g256::BN2 == 0 && K % 32 == 0;
   if (tile == OVG_TILE_128) return 0;
-  if (tile == OVG_TILE_256) return legal ? 1 : -1;
+  if (tile == OVG_TILE_256 || tile == OVG_TILE_256X) return legal ? 1 : -1;
   if (tile != OVG_TILE_AUTO) return -1;
   if (!legal || !light_epilogue_or_long_k || M < 20000) return 0;
   return 1;
@@ -596,7 +743,7 @@ int launch_linear(const ovg_linear_params& p, hipStream_t st) {
   const int big = choose_256(p.tile, sizeof(T) == 2, p.M, p.N, p.K, p.epilogue != OVG_EPI_RES || p.K >= 2048);
   if (big < 0) return OVG_E_ARG;
   if constexpr (sizeof(T) == 2) {
-    if (big) return launch_linear256<T>(p, st);
+    if (big) return launch_linear256<T>(p, st, p.tile == OVG_TILE_256X);
   }
   return launch_linear128<T>(p, st);
 }
@@ -653,11 +800,11 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
     const dim3 grid2((unsigned)(((p->M + g256::BM2 - 1) / g256::BM2) * ntc));
     const int ntg2 = ntc | (TILE_GROUP256 << 16);
     if (p->dtype == OVG_BF16) {
-      static const int ok = allow_big_lds(qkv256_kernel<bf16_t>, g256::LDS_BYTES + ROPE_LDS_BYTES);
+      const int ok = allow_big_lds(qkv256_kernel<bf16_t>, g256::LDS_BYTES + ROPE_LDS_BYTES);
       if (ok != OVG_OK) return ok;
       OVG_LAUNCH((qkv256_kernel<bf16_t>), grid2, dim3(512), g256::LDS_BYTES + ROPE_LDS_BYTES, st, *p, ntb, ntg2);
     } else {
-      static const int ok = allow_big_lds(qkv256_kernel<f16_t>, g256::LDS_BYTES + ROPE_LDS_BYTES);
+      const int ok = allow_big_lds(qkv256_kernel<f16_t>, g256::LDS_BYTES + ROPE_LDS_BYTES);
       if (ok != OVG_OK) return ok;
       OVG_LAUNCH((qkv256_kernel<f16_t>), grid2, dim3(512), g256::LDS_BYTES + ROPE_LDS_BYTES, st, *p, ntb, ntg2);
     }

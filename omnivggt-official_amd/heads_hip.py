@@ -16,6 +16,7 @@ Differences from the reference's arithmetic (all exact in real arithmetic, measu
 """
 import torch
 
+from . import lib as L
 from . import ops
 from .heads import uv_position_embedding
 
@@ -165,6 +166,14 @@ class HipCameraHead:
     on first use per device / dtype. One C call per batch element issues all ~165 launches of the four rounds."""
 
     def __init__(self, head):
+        # the kernel hard-codes the reference's default head: absT_quaR_FoV activations (translation / quaternion linear,
+        # field of view ReLU: heads/camera_head.py:37-41, head_act.py:12-35), dim 2048, <= 4 trunk blocks. A wrapped module
+        # that says otherwise (e.g. the reference's own CameraHead built with other arguments) is refused, not mis-served.
+        for attr, want in (("trans_act", "linear"), ("quat_act", "linear"), ("fl_act", "relu")):
+            if hasattr(head, attr) and getattr(head, attr) != want:
+                raise ValueError("HipCameraHead implements %s='%s' only (got '%s')" % (attr, want, getattr(head, attr)))
+        if len(head.trunk) > L.CAMERA_MAX_TRUNK or head.token_norm.weight.numel() != 2048:
+            raise ValueError("HipCameraHead needs dim 2048 and at most %d trunk blocks" % L.CAMERA_MAX_TRUNK)
         self.head = head
         self._packed = None
         self._key = None

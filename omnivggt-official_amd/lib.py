@@ -14,8 +14,8 @@ OVG_BF16, OVG_F16, OVG_F32 = 0, 1, 2
 EPI_STORE, EPI_GELU, EPI_RES, EPI_PATCH = 0, 1, 2, 3
 OVG_MAX_SEG = 8
 KV_TILE = 64
-ABI_VERSION = 6
-TILE_AUTO, TILE_128, TILE_256 = 0, 1, 2
+ABI_VERSION = 7
+TILE_AUTO, TILE_128, TILE_256, TILE_256X = 0, 1, 2, 3
 
 ERRORS = {0: "OVG_OK", -1: "OVG_E_ARG", -2: "OVG_E_DTYPE", -3: "OVG_E_LAUNCH", -4: "OVG_E_UNSUPPORTED"}
 
@@ -49,7 +49,8 @@ class KvSegment(C.Structure):
 class AttnParams(C.Structure):
     _fields_ = [("q", vp), ("nq", i64), ("nq_pad", i64), ("seg", KvSegment * OVG_MAX_SEG), ("nseg", i32),
                 ("out", vp), ("ldo", i64), ("BH", i64), ("dtype", i32), ("variant", i32),
-                ("kv_heads", i32), ("out_bh_stride", i64), ("lse", vp), ("kv_splits", i32), ("ws_part", vp), ("ws_lse", vp)]
+                ("kv_heads", i32), ("out_bh_stride", i64), ("lse", vp), ("kv_splits", i32), ("ws_part", vp), ("ws_lse", vp),
+                ("ws_part_bytes", i64), ("ws_lse_bytes", i64)]
 
 
 class AttnPlanOut(C.Structure):
@@ -78,7 +79,8 @@ class BlockParams(C.Structure):
                 ("ws_xn", vp), ("ws_q", vp), ("ws_k", vp), ("ws_vt", vp), ("ws_attn", vp), ("ws_hid", vp),
                 ("extra", KvSegment * OVG_MAX_SEG), ("nseg_extra", i32), ("local_seg_index", i32),
                 ("attn_variant", i32), ("qkv_part", i32), ("ev_attn_start", vp), ("ev_attn_stop", vp),
-                ("skip_attention", i32), ("gemm_tile", i32), ("ws_attn_part", vp), ("ws_attn_lse", vp), ("attn_kv_splits", i32)]
+                ("skip_attention", i32), ("gemm_tile", i32), ("ws_attn_part", vp), ("ws_attn_lse", vp), ("attn_kv_splits", i32),
+                ("ws_attn_part_bytes", i64), ("ws_attn_lse_bytes", i64)]
 
 
 class BlockWorkspace(C.Structure):
@@ -160,6 +162,11 @@ class CameraHeadParams(C.Structure):
                 ("pb1_w", vp), ("pb1_b", vp), ("pb2_w", vp), ("pb2_b", vp), ("ws", vp), ("ws_bytes", i64), ("out", vp)]
 
 
+class CameraTablesParams(C.Structure):
+    _fields_ = [("extrinsics", vp), ("intrinsics", vp), ("index", vp), ("B", i32), ("S", i32), ("Sc", i32), ("H", i32), ("W", i32), ("G", i32),
+                ("pose_w", vp), ("pose_b", vp), ("adapt_w", vp), ("adapt_b", vp), ("enc", vp), ("emb", vp), ("tables", vp)]
+
+
 # every entry point of include/omnivggt_hip.h: name -> (restype, argtypes)
 SYMBOLS = {
     "ovg_abi_version": (i32, []),
@@ -189,6 +196,7 @@ SYMBOLS = {
     "ovg_pack_weights": (i32, [C.POINTER(PackWeightsParams), vp]),
     "ovg_camera_head": (i32, [C.POINTER(CameraHeadParams), vp]),
     "ovg_camera_head_workspace_bytes": (i64, [i32, i32]),
+    "ovg_camera_tables": (i32, [C.POINTER(CameraTablesParams), vp]),
 }
 
 
@@ -211,7 +219,7 @@ def load(build_if_missing=True):
         if not build_if_missing or not B.have_hipcc():
             raise OvgError("libomnivggt_hip.so is %s (run __graft_entry__.build()); there is no fallback path"
                            % ("missing" if not os.path.exists(LIB_PATH) else "stale: csrc/ changed since it was built"))
-        B.build()
+        B.build()      # takes an exclusive file lock and re-checks the stamp under it: N ranks starting together build once
     # torch bundles its own libamdhip64.so.7; it MUST be in the process before our library is
     # dlopen'ed, otherwise the loader maps /opt/rocm's copy for us and torch's copy for torch:
     # two HIP runtimes, and our launches on torch's streams fail (OVG_E_LAUNCH).

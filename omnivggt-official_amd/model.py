@@ -9,10 +9,12 @@
 `compute_dtype` selects the aggregator arithmetic: torch.float32 (the DEFAULT, like the reference, which runs
 fp32 end to end -- inference.py has no autocast, omnivggt.py:45 disables it around the heads: exact-f32 MFMA,
 matches the reference CPU path to <= 1e-4 relative), torch.bfloat16 or torch.float16 (throughput modes, an explicit
-opt-in: ~14x faster, tokens within the bf16-autocast twin's own error, profiles/r02_lowprec_parity.txt).  The camera head always runs in f32 PyTorch, like the reference (autocast
-disabled, omnivggt.py:45).  The two DPT heads run on the HIP kernels (heads_hip.py, 16-bit NHWC
-implicit-GEMM convolutions) in the 16-bit modes and as f32 PyTorch modules in the parity mode;
-`hip_heads=False` forces the PyTorch heads everywhere.
+opt-in: ~14x faster, tokens within the bf16-autocast twin's own error, profiles/r02_lowprec_parity.txt).  Heads: in the f32 parity
+mode all three run as f32 PyTorch modules, like the reference (autocast disabled around them, omnivggt.py:45). In the 16-bit
+modes the two DPT heads run on the HIP kernels (heads_hip.py: 16-bit NHWC implicit-GEMM convolutions) and the camera head on
+ovg_camera_head (16-bit weight streams; residual stream, statistics, softmax and the pose accumulation in f32);
+`hip_heads=False` forces the PyTorch heads everywhere, `hip_camera_head=False` only the camera head (pose_enc then carries
+no 16-bit head error: 3.6 ms instead of 1.2 ms at 8 views).
 """
 import torch
 import torch.nn as nn
@@ -30,9 +32,10 @@ except Exception:  # pragma: no cover - optional
 
 class OmniVGGT(nn.Module, _HubMixin):
     def __init__(self, img_size=518, patch_size=14, embed_dim=1024, depth=24, dino_depth=24,
-                 compute_dtype=torch.float32, dpt_layers=(4, 11, 17, 23), hip_heads=True):
+                 compute_dtype=torch.float32, dpt_layers=(4, 11, 17, 23), hip_heads=True, hip_camera_head=True):
         super().__init__()
         self.hip_heads = hip_heads
+        self.hip_camera_head = hip_camera_head
         self.aggregator = ZeroAggregator(img_size=img_size, patch_size=patch_size, embed_dim=embed_dim, depth=depth,
                                          dino_depth=dino_depth, pose_hidden_dim=9, compute_dtype=compute_dtype)
         layers = tuple(min(l, depth - 1) for l in dpt_layers)
@@ -49,7 +52,7 @@ class OmniVGGT(nn.Module, _HubMixin):
     def _camera(self, cam_tokens):
         dt = self.aggregator.compute_dtype
         toks = cam_tokens[-1]
-        if self.hip_heads and dt in (torch.bfloat16, torch.float16) and toks.is_cuda and toks.shape[1] <= 4096:
+        if self.hip_heads and self.hip_camera_head and dt in (torch.bfloat16, torch.float16) and toks.is_cuda and toks.shape[1] <= 4096:
             return self._hip_cam(cam_tokens, dtype=dt)
         return self.camera_head(cam_tokens)
 

@@ -19,6 +19,10 @@ def pad_to(n, m):
     return (n + m - 1) // m * m
 
 
+def nbytes(t):
+    return 0 if t is None else t.numel() * t.element_size()
+
+
 def _chk_dev(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -168,6 +172,7 @@ def flash_attn(q, segments, nq, dtype, out=None, variant=0, kv_heads=0, head_maj
     if split_ws is not None and split_ws[0] is not None:
         _chk_dev(*split_ws)
         p.ws_part, p.ws_lse = L.ptr(split_ws[0]), L.ptr(split_ws[1])
+        p.ws_part_bytes, p.ws_lse_bytes = nbytes(split_ws[0]), nbytes(split_ws[1])
     L.call("ovg_flash_attn", p, _stream())
     return out
 
@@ -377,6 +382,39 @@ def camera_head(tokens, W, dtype, iters=4, ws=None):
             setattr(p.blk[i], name, L.ptr(blk[name]))
     p.ws, p.ws_bytes, p.out = L.ptr(ws), ws.numel() * ws.element_size(), L.ptr(out)
     L.call("ovg_camera_head", p, _stream())
+    return out
+
+
+def camera_tables(extrinsics, intrinsics, index, S, hw, pose_w, pose_b, adapt_w, adapt_b, out=None):
+    """Camera-modality injection tables [G, B*S, 1024] f32 built on the device in <= 3 launches, no host round trip
+    (ovg_camera_tables). extrinsics [B,S,3,4] / intrinsics [B,S,3,3] f32 device tensors (ignored when index is None);
+    index: int32 DEVICE tensor [Sc] of the views that carry a GT camera, or None; pose_w [G*1024, 9], pose_b [G*1024],
+    adapt_w [G,1024,1024], adapt_b [G,1024] f32."""
+    _chk_dev(pose_w, pose_b, adapt_w, adapt_b, index, out)
+    G = adapt_b.shape[0]
+    Sc = 0 if index is None else int(index.numel())
+    B = 1 if Sc == 0 else extrinsics.shape[0]
+    dev = adapt_b.device
+    if out is None:
+        out = torch.empty(G, B * S, C, device=dev, dtype=torch.float32)
+    p = L.CameraTablesParams()
+    p.B, p.S, p.Sc, p.H, p.W, p.G = B, S, Sc, int(hw[0]), int(hw[1]), G
+    p.pose_w, p.pose_b, p.adapt_w, p.adapt_b, p.tables = L.ptr(pose_w), L.ptr(pose_b), L.ptr(adapt_w), L.ptr(adapt_b), L.ptr(out)
+    keep = None
+    if Sc:
+        _chk_dev(extrinsics, intrinsics)
+        if index.dtype != torch.int32 or not index.is_contiguous():
+            raise L.OvgError("camera_tables: index must be a contiguous int32 device tensor")
+        ext = extrinsics.detach().to(torch.float32).contiguous()
+        intr = intrinsics.detach().to(torch.float32).contiguous()
+        if tuple(ext.shape[1:]) != (S, 3, 4) or tuple(intr.shape) != (B, S, 3, 3):
+            raise L.OvgError("camera_tables: extrinsics must be [B,S,3,4] and intrinsics [B,S,3,3]")
+        enc = torch.empty(B * Sc, 9, device=dev, dtype=torch.float32)
+        emb = torch.empty(G, B * Sc, C, device=dev, dtype=torch.float32)
+        keep = (ext, intr, enc, emb)
+        p.extrinsics, p.intrinsics, p.index, p.enc, p.emb = L.ptr(ext), L.ptr(intr), L.ptr(index), L.ptr(enc), L.ptr(emb)
+    L.call("ovg_camera_tables", p, _stream())
+    del keep          # the caching allocator keeps freed blocks valid for work already queued on this stream
     return out
 
 

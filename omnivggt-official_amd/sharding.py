@@ -299,27 +299,40 @@ class ViewSharding:
         else:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
 
-    def compare_modes(self, run, n_views, is_f32=False):
-        """Diagnostic used by bench.py: run one sharded forward in each exchange form the shapes admit and report the
-        max-rel difference between them (MAX over ranks). `run()` must execute one forward and return a tensor of it.
+    def compare_modes(self, run, n_views, is_f32=False, on_stage=None):
+        """Diagnostic used by bench.py (before it times anything): run one sharded forward in each exchange form the shapes
+        admit and report the max-rel difference between them (MAX over ranks) and each form's wall time. `run()` must execute
+        one forward and return a tensor of it; on_stage(text) is called before each form (bench.py's watchdog heartbeat).
         No exception handling around collectives: a failing RCCL call must crash the job, not desynchronise it."""
+        import time
         saved = self.mode
-        report = {"modes": ["allgather"]}
-        self.mode = "allgather"
-        ref = run().float().clone()
+        report = {"modes": ["allgather"], "seconds": {}}
+
+        def timed(mode):
+            self.mode = mode
+            if on_stage is not None:
+                on_stage("compare_modes: one forward in the %s form" % mode)
+            t0 = time.perf_counter()
+            out = run().float().clone()
+            if out.is_cuda:
+                torch.cuda.synchronize(out.device)
+            report["seconds"][mode] = round(time.perf_counter() - t0, 4)
+            return out
+
         try:
-            resolve_mode("heads", n_views, self.world, is_f32)
-        except ValueError:
-            self.mode = saved
+            ref = timed("allgather")
+            try:
+                resolve_mode("heads", n_views, self.world, is_f32)
+            except ValueError:
+                return report
+            got = timed("heads")
+            err = torch.tensor([float((got - ref).abs().max() / ref.abs().max().clamp(min=1e-30))], device=ref.device)
+            self._all_reduce_max(err)
+            report["modes"].append("heads")
+            report["max_rel_heads_vs_allgather"] = float(err.item())
             return report
-        self.mode = "heads"
-        got = run().float()
-        err = torch.tensor([float((got - ref).abs().max() / ref.abs().max().clamp(min=1e-30))], device=ref.device)
-        self._all_reduce_max(err)
-        self.mode = saved
-        report["modes"].append("heads")
-        report["max_rel_heads_vs_allgather"] = float(err.item())
-        return report
+        finally:
+            self.mode = saved
 
     # ---------------------------------------------------------------------------------------------------------
     def forward(self, agg, images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index):

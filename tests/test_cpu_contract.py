@@ -60,7 +60,7 @@ def test_ctypes_struct_layout_matches_c():
              "ovg_unproject_params": L.UnprojectParams, "ovg_heads_to_tokens_params": L.HeadsToTokensParams,
              "ovg_attn_merge_params": L.AttnMergeParams, "ovg_block_workspace": L.BlockWorkspace,
              "ovg_pack_weights_params": L.PackWeightsParams, "ovg_camera_block_weights": L.CameraBlockWeights,
-             "ovg_camera_head_params": L.CameraHeadParams}
+             "ovg_camera_head_params": L.CameraHeadParams, "ovg_camera_tables_params": L.CameraTablesParams}
     src = '#include <stdio.h>\n#include "%s"\nint main(){\n' % HEADER
     for name in pairs:
         src += 'printf("%s %%zu\\n", sizeof(%s));\n' % (name, name)
@@ -89,6 +89,7 @@ def test_argument_validation_without_gpu():
     assert not hasattr(lib, "ovg_debug_set")          # ABI 4: no process-global knobs left in the library
     assert lib.ovg_camera_head(ctypes.byref(L.CameraHeadParams()), None) == -1
     assert lib.ovg_camera_head(None, None) == -1
+    assert lib.ovg_camera_tables(ctypes.byref(L.CameraTablesParams()), None) == -1 and lib.ovg_camera_tables(None, None) == -1
     # the camera head's workspace query is a pure host function: S tokens x (f32 token / residual / pose / 32768 partial
     # columns + 16-bit LN, embed, qkv, attention and hidden buffers), every piece rounded up to 256 bytes
     r = lambda n: (n + 255) // 256 * 256

@@ -73,6 +73,13 @@ def test_gemm256_kernels_every_epilogue_ragged_m():
     _assert_clean()
 
 
+def test_gemm256_r03_epilogue_forms():
+    """OVG_TILE_256X: the residual epilogue through LDS-DMA (full tiles; ragged tiles and the injection variant fall back) and
+    the polynomial GELU, every epilogue / ragged M / in-place residual again."""
+    st.test_gemm256(False, tile=L.TILE_256X, auto_is=False)
+    _assert_clean()
+
+
 def test_global_attention_at_bench_key_counts():
     """N = 10 992 / 21 984 in full, N = 87 936 on sampled rows: the launches the bench times."""
     st.test_attn_big(False)

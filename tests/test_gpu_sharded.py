@@ -109,9 +109,24 @@ def test_two_uneven_shards_emulated_match_monolithic(dtype, tol):
     inputs = (inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
     with torch.no_grad():
         ref, _ = agg(*inputs)
-    P, C = agg.tokens_per_view, 1024
+    P = agg.tokens_per_view
     parts = sharding.partition(S, 2)
     assert parts == [(0, 2), (2, 3)]
+    ranks = _emulate_allgather(agg, inputs, parts, P)
+    for i in range(agg.depth):
+        got = torch.cat([st["outs"][i] for st in ranks], dim=1)
+        assert got.shape == ref[i].shape
+        assert common.max_rel(got.cpu(), ref[i].cpu()) <= tol
+
+
+def _emulate_allgather(agg, inputs, parts, P):
+    """len(parts) ranks of the K / V^T all-gather form run sequentially in one process on the real HipExecutor steps: per rank
+    LN1 + k/v-only QKV launch, q-only QKV launch, launch A over the local keys (+ log-sum-exp), launch B over the world - 1
+    gathered remote segments (K / V^T padded to the largest shard, per-segment valid counts), ovg_attn_merge, proj + MLP.
+    The all-gather itself is a torch.stack of the ranks' buffers. Ranks with equal shard sizes share the LN / attention /
+    hidden scratch (agg.workspace), so each rank finishes its q launch before the next rank's LayerNorm reuses `xn`."""
+    C = 1024
+    world = len(parts)
     counts = [(h - l) * P for l, h in parts]
     max_local = max(h - l for l, h in parts)
     ranks = []
@@ -129,19 +144,17 @@ def test_two_uneven_shards_emulated_match_monolithic(dtype, tol):
                 k, vt = st["ex"].global_kv(i, st["ws_g"], buf[:, :C], buf[:, C:])
                 ks.append(k.clone())
                 vs.append(vt.clone())
+                st["ex"].global_q(i, st["ws_g"], buf[:, :C], buf[:, C:])      # q stays in this rank's own q buffer
             kg, vg = torch.stack(ks), torch.stack(vs)                  # the all-gather
             for r, st in enumerate(ranks):
                 buf = st["outs"][i].view(-1, 2 * C)
                 n = (st["hi"] - st["lo"]) * P
-                st["ex"].global_q(i, st["ws_g"], buf[:, :C], buf[:, C:])
-                st["ex"].attend_local(i, st["ws_g"], n, want_lse=True)                       # launch A: local keys
-                st["ex"].attend_remote(i, st["ws_g"], kg, vg, counts, r, n)                   # launch B: the other rank's keys
-                st["ex"].merge_finish(i, st["ws_g"], buf[:, :C], buf[:, C:], n, merged=True)  # log-sum-exp merge + proj + MLP
+                st["ex"].attend_local(i, st["ws_g"], n, want_lse=world > 1)                   # launch A: local keys
+                if world > 1:
+                    st["ex"].attend_remote(i, st["ws_g"], kg, vg, counts, r, n)               # launch B: every other rank's keys
+                st["ex"].merge_finish(i, st["ws_g"], buf[:, :C], buf[:, C:], n, merged=world > 1)   # log-sum-exp merge + proj + MLP
                 st["x"] = buf[:, C:]
-    for i in range(agg.depth):
-        got = torch.cat([st["outs"][i] for st in ranks], dim=1)
-        assert got.shape == ref[i].shape
-        assert common.max_rel(got.cpu(), ref[i].cpu()) <= tol
+    return ranks
 
 
 def test_two_even_shards_head_parallel_emulated_match_monolithic():
@@ -164,6 +177,24 @@ def test_two_even_shards_head_parallel_emulated_match_monolithic():
     # force the two-group pipeline for this small case (head_groups() itself would keep one launch at 2 x 1374 tokens)
     orig_groups = sharding.head_groups
     sharding.head_groups = lambda h, world=1, n_tokens=None: orig_groups(h)
+    try:
+        ranks = _emulate_heads(agg, inputs, world, parts, P)
+    finally:
+        sharding.head_groups = orig_groups          # a failure above must not leak the patch into later tests
+    for i in range(agg.depth):
+        got = torch.cat([st["outs"][i] for st in ranks], dim=1)
+        assert got.shape == ref[i].shape
+        assert common.max_rel(got.cpu(), ref[i].cpu()) <= 2e-2
+
+
+def _emulate_heads(agg, inputs, world, parts, P):
+    """`world` ranks of the head-parallel (all-to-all) form run sequentially in one process on the real HipExecutor steps:
+    per-rank QKV for all 16 heads, per-head-group chunk exchange (= the list-form all_to_all, done with copies), attention
+    over (source rank, head) batch entries with kv_heads = heads of the group and `world` K / V^T segments (with whatever
+    split-KV factor the library's plan picks for that launch), head-major outputs returned into global head order,
+    head-major -> token-major, epilogue without the attention launch. Returns the per-rank states (outs = their views)."""
+    C = 1024
+    hpr = 16 // world
     ranks = []
     with torch.no_grad():
         for r, (lo, hi) in enumerate(parts):
@@ -179,7 +210,7 @@ def test_two_even_shards_head_parallel_emulated_match_monolithic():
                 st["ex"].frame_block(i, st["ws_f"], st["x"], buf[:, :C], st["tables"][i + 1][st["lo"]:st["hi"]].contiguous(), P)
                 q, k, vt = st["ex"].global_qkv(i, st["ws_g"], buf[:, :C], buf[:, C:])
                 sent.append((q.clone(), k.clone(), vt.clone()))      # the global workspace is shared between the emulated ranks
-            for gi in range(2):
+            for gi in range(len(ranks[0]["xb"]["groups"])):
                 for r, st in enumerate(ranks):                        # inbound exchange of group gi: rank r receives from every s
                     g = st["xb"]["groups"][gi]
                     for s in range(world):
@@ -194,11 +225,7 @@ def test_two_even_shards_head_parallel_emulated_match_monolithic():
                 buf = st["outs"][i].view(-1, 2 * C)
                 st["ex"].global_finish(i, st["ws_g"], buf[:, :C], buf[:, C:], st["xb"]["o_back"], n)
                 st["x"] = buf[:, C:]
-    sharding.head_groups = orig_groups
-    for i in range(agg.depth):
-        got = torch.cat([st["outs"][i] for st in ranks], dim=1)
-        assert got.shape == ref[i].shape
-        assert common.max_rel(got.cpu(), ref[i].cpu()) <= 2e-2
+    return ranks
 
 
 def _rccl_worker(rank, world, port, result_dir):
@@ -242,3 +269,69 @@ def test_two_process_rccl_both_exchange_forms(tmp_path):
     mp.spawn(_rccl_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     res = torch.load(os.path.join(str(tmp_path), "rccl.pt"))
     assert res["allgather"] <= 2e-2 and res["heads"] <= 2e-2 and res["uneven"] <= 2e-2, res
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The EIGHT-rank run of the scaling bench, proven on one GPU (round-2 review: the emulation covered 2 ranks / 2 segments
+# only): every rank's real launches -- 8 K / V^T segments, 2 heads per rank (kv_heads = 2, 16 (source rank, head) batch
+# entries), the split-KV factor the library's plan picks for that launch, uneven shards with padded buffers and per-segment
+# valid counts -- stitched together and compared with the monolithic forward of the same weights.
+# Reference semantics preserved: one softmax over ALL S * 1374 keys per query (aggregator.py:312-341).
+# ----------------------------------------------------------------------------------------------------------------------
+def _stitched_vs_monolithic(agg, ranks, ref, tol):
+    worst = 0.0
+    for i in range(agg.depth):
+        got = torch.cat([st["outs"][i] for st in ranks], dim=1)
+        assert got.shape == ref[i].shape
+        assert torch.isfinite(got).all()
+        worst = max(worst, common.max_rel(got.cpu(), ref[i].cpu()))
+    assert worst <= tol, worst
+    return worst
+
+
+@pytest.mark.parametrize("S,dgi,cgi", [(16, [1, 9, 14], [0, 5, 15]), (64, [], [])])
+def test_eight_ranks_head_parallel_emulated_match_monolithic(S, dgi, cgi):
+    """8 ranks x S/8 views, head-parallel exchange. S = 64 is the per-rank shape of the 8-GPU scaling bench (configs[3]):
+    16 batch entries x 10 992 queries x 8 segments of 10 992 keys, one head group (head_groups keeps 2 heads together), and
+    the plan's 4-way split-KV -- asserted, so a plan change cannot silently drop the coverage."""
+    from omnivggt_official_amd import ops
+    L.require_gpu()
+    m = build(1, 1, torch.bfloat16)
+    agg = m.aggregator
+    world = 8
+    inp = common.inputs_for(S, DEV)
+    inputs = (inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
+    with torch.no_grad():
+        ref, _ = agg(*inputs)
+    P = agg.tokens_per_view
+    parts = sharding.partition(S, world)
+    n = (S // world) * P
+    assert sharding.head_groups(16 // world, world, n) == [(0, 2)]
+    plan = ops.attn_plan(16, n, [n] * world, torch.bfloat16)
+    if S == 64:
+        assert plan["splits"] == 4, plan
+    ranks = _emulate_heads(agg, inputs, world, parts, P)
+    worst = _stitched_vs_monolithic(agg, ranks, ref, 2e-2)
+    print("8 emulated ranks, head-parallel, S=%d (plan: %d-row q tiles, split-KV x%d): max-rel vs monolithic %.2e" % (S, plan["q_tile"], plan["splits"], worst))
+
+
+@pytest.mark.parametrize("S,dtype,tol", [(20, torch.bfloat16, 2e-2), (20, torch.float32, 1e-5), (64, torch.bfloat16, 2e-2)])
+def test_eight_ranks_allgather_emulated_match_monolithic(S, dtype, tol):
+    """8 ranks, K / V^T all-gather form (the north star's collective). S = 20 shards unevenly (3/3/3/3/2/2/2/2): the 2-view
+    ranks' buffers are padded to 3 views and their segments carry nk = 2 * 1374; launch B walks 7 remote segments. S = 64 is
+    the scaling bench's per-rank shape in this form. f32 = the parity mode's sharded path."""
+    L.require_gpu()
+    m = build(1, 1, dtype)
+    agg = m.aggregator
+    world = 8
+    dgi, cgi = ([1, 7, 19], [0, 3, 18]) if S == 20 else ([], [])
+    inp = common.inputs_for(S, DEV)
+    inputs = (inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
+    with torch.no_grad():
+        ref, _ = agg(*inputs)
+    parts = sharding.partition(S, world)
+    if S == 20:
+        assert [h - l for l, h in parts] == [3, 3, 3, 3, 2, 2, 2, 2]
+    ranks = _emulate_allgather(agg, inputs, parts, agg.tokens_per_view)
+    worst = _stitched_vs_monolithic(agg, ranks, ref, tol)
+    print("8 emulated ranks, K/V all-gather, S=%d %s: max-rel vs monolithic %.2e" % (S, str(dtype).replace("torch.", ""), worst))

@@ -1,4 +1,4 @@
-"""World-size-2 CPU (gloo) run of the view-sharded control flow
+"""World-size-2 / 4 / 8 CPU (gloo) runs of the view-sharded control flow
 (omnivggt-official_amd/sharding.py) with an ORACLE-backed executor in place of the HIP one:
 validates the partition, the K/V^T all-gather plumbing (uneven shards, padded buffers,
 per-segment valid counts, rank-ordered segments), the camera-token gather and the gathered
@@ -209,6 +209,29 @@ def test_view_sharded_forward_matches_monolithic_oracle(tmp_path, S, dgi, cgi, h
         ref, _ = orc.aggregator_forward(sd, inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi,
                                         depth_layers=DEPTH, dino_layers=DINO)
     assert len(sharded) == DEPTH
+    for a, b in zip(sharded, ref):
+        assert a.shape == b.shape == (1, S, P, 2048)
+        assert common.max_rel(a, b) < 2e-5
+
+
+@pytest.mark.parametrize("world,S,dgi,cgi,mode", [(4, 8, [1, 6], [0, 5], "auto"), (4, 6, [5], [0, 3], "auto"),
+                                                    (8, 8, [2], [0, 7], "heads"), (8, 11, [0, 10], [1, 9], "allgather"),
+                                                    (8, 16, [], [3], "choose")])
+def test_view_sharded_forward_at_world_4_and_8(tmp_path, world, S, dgi, cgi, mode):
+    """The rank counts of the scaling bench (round-2 review: only world 2 was covered): 4 ranks even (head-parallel, 4 heads
+    per rank in two pipelined groups of 2) and uneven (2/2/1/1 -> all-gather with padded shards); 8 ranks head-parallel
+    (2 heads per rank, one group, 8 inbound chunks per exchange), 8 ranks uneven (2/2/2/1/1/1/1/1: launch B walks 7 remote
+    segments of two different lengths) and bench.py's pre-flight (both forms on the same input, compared across ranks).
+    Small frames (210 x 266) keep 8 single-threaded oracle processes inside the CPU budget."""
+    hw = (210, 266)
+    mp.spawn(_worker, args=(world, _free_port(), S, dgi, cgi, str(tmp_path), hw, mode), nprocs=world, join=True)
+    sharded = torch.load(os.path.join(str(tmp_path), "sharded.pt"))
+    sd = common.reduced_state_dict(DEPTH, DINO)
+    inp = orc.synthetic_inputs(S, hw=hw)
+    P = (hw[0] // 14) * (hw[1] // 14) + 5
+    with torch.no_grad():
+        ref, _ = orc.aggregator_forward(sd, inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi,
+                                        depth_layers=DEPTH, dino_layers=DINO)
     for a, b in zip(sharded, ref):
         assert a.shape == b.shape == (1, S, P, 2048)
         assert common.max_rel(a, b) < 2e-5
