@@ -260,7 +260,10 @@ def main():
         cfg = "2" if (args.aux and S == 16) else ("4" if (args.partial_aux and S == 128) else ("-" if (args.aux or args.partial_aux) else {8: "1", 64: "3"}.get(S, "-")))
         form = ""
         if shard is not None:
-            form = ", " + {"heads": "head-parallel all-to-all in 2 pipelined head groups", "allgather": "K/V all-gather, local keys first + log-sum-exp merge"}[shard.last_mode]
+            from omnivggt_official_amd.sharding import head_groups
+            ng = len(head_groups(16 // world, world, n_local * P_TOK)) if 16 % world == 0 else 1
+            form = ", " + {"heads": "head-parallel all-to-all, %s" % ("2 pipelined head groups" if ng == 2 else "1 head group per rank"),
+                           "allgather": "K/V all-gather, local keys first + log-sum-exp merge"}[shard.last_mode]
         res = {
             "value": round(S * steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 3),
             "config": {"workload": "OmniVGGT aggregator forward, %d views 518x518 %s (BASELINE configs[%s]), view-sharded over %d GPU(s)"

@@ -182,7 +182,7 @@ OVG_DEV void gemm_mainloop(const T* __restrict__ X, int64_t ldx, const T* __rest
 // Now: the per-column vectors (bias, gamma) are loaded ONCE per wave, the row loop bodies are branch-free (row
 // indices clamped for the loads, only the store is predicated), so the four residual / table loads of a row block
 // -- and, registers permitting, the next row block's -- are in flight together.
-template <typename T, int EPI, bool OUT_F32, int MT, bool INJECT, int XP = 0>   // XP = 1: r03 epilogue forms (OVG_TILE_256X): polynomial GELU (the residual form of XP is res_epilogue_dma)
+template <typename T, int EPI, bool OUT_F32, int MT, bool INJECT, int XP = 0>   // XP = 1 (OVG_TILE_256X, A/B knob): the r02 erf_as GELU instead of the polynomial one
 OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int n_w0) {
   const int M = (int)p.M, N = (int)p.N;
   const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
@@ -203,8 +203,10 @@ OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)
   // output may alias the residual (fc2 runs in place), so the compiler may not move a later block's loads above an
   // earlier block's stores on its own; different row blocks never touch the same rows, so doing it by hand is safe.
   // AH: 0 in the 128 x 128 kernels (3 workgroups per CU hide the latency and must stay <= 168 VGPRs), 1 in the 256 x 256
-  // kernels (1 workgroup per CU: nobody else hides it). A deeper register ring does not fit beside the 128 accumulators
-  // (AH = 3 spilled 380 bytes): the residual epilogue of full tiles goes through LDS-DMA instead (res_epilogue_dma below).
+  // kernels (1 workgroup per CU: nobody else hides it). r03 A/B (profiles/r03_gemm_epilogue_forms_ab.txt): a deeper register
+  // ring does not fit beside the 128 accumulators (AH = 3 spilled 380 bytes), and fetching the residual tile by LDS-DMA
+  // through the idle ring (16 KB per wave in flight, no registers) gained 0.4 % on proj and 0.8 % on fc2 -- the residual
+  // epilogue is not bound by load latency but by the 0.9 GB it moves (3 TB/s averaged over the launch); removed again.
   constexpr bool kRowLoads = (EPI == OVG_EPI_RES || EPI == OVG_EPI_PATCH);
   constexpr int AH = !kRowLoads ? 0 : (MT == 8 ? 1 : 0);
   constexpr int NS = AH + 1;                            // ring slots; every index below is a compile-time constant after unrolling
@@ -257,10 +259,10 @@ OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)
     for (int nt = 0; nt < 4; ++nt) {
       v[nt] = acc[nt][mt] + bias[nt];
       if constexpr (EPI == OVG_EPI_GELU) {
-        if constexpr (!(XP && sizeof(T) == 2)) {     // the XP form handles the four column blocks of the row block together, below
+        if constexpr (XP || sizeof(T) == 4) {        // f32 parity mode: libm erff; XP (A/B knob OVG_TILE_256X): the r02 erf_as form; else the polynomial form below
           v[nt][0] = gelu_erf<T>(v[nt][0]); v[nt][1] = gelu_erf<T>(v[nt][1]); v[nt][2] = gelu_erf<T>(v[nt][2]); v[nt][3] = gelu_erf<T>(v[nt][3]);
         }
-        if constexpr (std::is_same<T, f16_t>::value && !(XP && sizeof(T) == 2)) {
+        if constexpr (std::is_same<T, f16_t>::value && XP) {
           // f16 range guard: the hidden activation is the one 16-bit tensor fed by an unnormalised f32 sum (DINOv2-style
           // massive activations reach 1e3..1e4 after fc1); saturate at the largest finite f16 instead of storing +inf
           // (inf * 0-weight = NaN in fc2). GELU is bounded below by -0.17, so only the upper side needs it.
@@ -272,7 +274,7 @@ OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)
       if constexpr (EPI == OVG_EPI_RES && INJECT) v[nt] += on[cs] * inj[cs][nt];
       if constexpr (EPI == OVG_EPI_PATCH) v[nt] += ex[cs][nt];
     }
-    if constexpr (EPI == OVG_EPI_GELU && XP && sizeof(T) == 2) {
+    if constexpr (EPI == OVG_EPI_GELU && !XP && sizeof(T) == 2) {
       gelu_poly16(v);
       if constexpr (std::is_same<T, f16_t>::value) {
 #pragma unroll
@@ -292,81 +294,6 @@ OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)
         }
       }
     }
-  }
-}
-
-// Residual epilogue of the 256 x 256 kernels with the residual tile fetched by LDS-DMA (XP form, no injection, full tiles):
-//   y[m, n] = res[m, n] + gamma[n] * (acc + bias[n])          (attention.py:75 / mlp.py:38 + layer_scale.py:27 + block.py:105-106)
-// The register-prefetch form above keeps ONE row block (4 x 16 B per lane) of residual in flight per wave and pays a memory round
-// trip per row block: 8 exposed round trips per wave, 23 us of proj's 50 us tile (profiles/r02_gemm_epilogue_mlp.txt). More
-// registers are not available (128 accumulators + bias + gamma). After the main loop, however, the 128 KB LDS ring is idle:
-// every wave owns 16 KB of it = FOUR row blocks of its 64 x 128 f32 block. All four are requested at once (16 LDS-DMA
-// instructions, no registers), a row block is consumed as soon as ITS four transfers have landed (counted vmcnt: in-order
-// retirement; the y stores count too on CDNA4 and are in the arithmetic below), and its slot is refilled with row block + 4
-// straight away -- 12-16 KB per wave in flight throughout instead of 4 KB.
-//   LDS image: instruction (slot, nt) -> 1 KB at wave_base + (slot * 4 + nt) * 1024, lane l at + 16 l: exactly the 16 bytes lane l
-//   needs for (row lr = l & 15, columns ncol + 16 nt .. + 3), so the read-back is one lane-linear (conflict-free) ds_read_b128.
-//   VMEM ops after group G_j (4 DMAs of row block j) when iteration j waits for it, S_i = the 4 stores of iteration i:
-//     j = 0: G1 G2 G3                          -> vmcnt(12)      j = 4: S1 G5 S2 G6 S3 G7      -> vmcnt(24)
-//     j = 1: G2 G3 S0 G4                       -> vmcnt(16)      j = 5: S2 G6 S3 G7 S4         -> vmcnt(20)
-//     j = 2: G3 S0 G4 S1 G5                    -> vmcnt(20)      j = 6: S3 G7 S4 S5            -> vmcnt(16)
-//     j = 3: S0 G4 S1 G5 S2 G6                 -> vmcnt(24)      j = 7: S4 S5 S6               -> vmcnt(12)
-//   WAR on a slot: the refill of slot j % 4 is issued after the ds_reads of row block j have RETURNED (s_waitcnt lgkmcnt(0)).
-// Only for tiles whose 128 rows are all live (the stores are then unconditional: the counts above are exact); the ragged last
-// m-tile and the injection variant (its table loads are compiler-visible VMEM ops whose waits would drain the DMA queue) take
-// the register form.
-template <typename T>
-OVG_DEV void res_epilogue_dma(const ovg_linear_params& p, const f32x4 (&acc)[4][8], const int m_w0, const int n_w0, unsigned char* lds) {
-  const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ncol = n_w0 + 4 * g;
-  f32x4 bias[4], gam[4];
-  if (p.bias != nullptr) {
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) bias[nt] = *reinterpret_cast<const f32x4*>(p.bias + ncol + nt * 16);
-  } else {
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) bias[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) gam[nt] = *reinterpret_cast<const f32x4*>(p.gamma + ncol + nt * 16);
-  // fold gamma * bias now: this USES the two vectors, so the compiler's wait for their loads sits here, in front of the first
-  // DMA, not in front of the first row block (where its vmcnt(0) would drain the sixteen transfers just issued)
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) bias[nt] = gam[nt] * bias[nt];
-  asm volatile("" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3]), "+v"(gam[0]), "+v"(gam[1]), "+v"(gam[2]), "+v"(gam[3]));
-
-  const uint32_t wbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds) + (uint32_t)wave * 16384u;
-  const float* rlane = p.res + (int64_t)(m_w0 + lr) * p.ldres + ncol;        // this lane's 16 bytes of row block 0, column block 0
-  float* ylane = static_cast<float*>(p.y) + (int64_t)(m_w0 + lr) * p.ldy + ncol;
-  const unsigned char* lread = lds + wave * 16384 + lane * 16;
-  auto issue = [&](int mt) {
-    const float* src = rlane + (int64_t)mt * 16 * p.ldres;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) lds_dma16(src + nt * 16, wbase + (uint32_t)(((mt & 3) * 4 + nt) * 1024));
-  };
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) issue(mt);
-#pragma unroll
-  for (int mt = 0; mt < 8; ++mt) {
-    // counted wait for group mt (table above)
-    if (mt == 0 || mt == 7) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (mt == 1 || mt == 6) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (mt == 2 || mt == 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    f32x4 ex[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) ex[nt] = *reinterpret_cast<const f32x4*>(lread + ((mt & 3) * 4 + nt) * 1024);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the reads have returned: the slot may be refilled
-    __builtin_amdgcn_sched_barrier(0);
-    float* yrow = ylane + (int64_t)mt * 16 * p.ldy;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const f32x4 v = ex[nt] + (gam[nt] * acc[nt][mt] + bias[nt]);
-      *reinterpret_cast<f32x4*>(yrow + nt * 16) = v;
-    }
-    __builtin_amdgcn_sched_barrier(0);                          // the 4 stores stay in front of the refill (the counts assume it)
-    if (mt + 4 < 8) issue(mt + 4);
   }
 }
 
@@ -622,12 +549,7 @@ __global__ __launch_bounds__(512) void linear256_kernel(ovg_linear_params p, int
   f32x4 acc[4][8];
   g256::mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds256, acc);
   const int wave = threadIdx.x >> 6;
-  const int m_w0 = m0 + (wave >> 2) * 128, n_w0 = n0 + (wave & 3) * 64;
-  if constexpr (EPI == OVG_EPI_RES && XP) {
-    // wave-uniform choice: all 128 rows of the wave live and no injection table -> residual by LDS-DMA through the idle ring
-    if (p.inject == nullptr && m_w0 + 128 <= M) { res_epilogue_dma<T>(p, acc, m_w0, n_w0, lds256); return; }
-  }
-  linear_epilogue<T, EPI, OUT_F32, 8, XP>(p, acc, m_w0, n_w0);
+  linear_epilogue<T, EPI, OUT_F32, 8, XP>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64);
 }
 
 template <typename T>
@@ -648,6 +570,77 @@ __global__ __launch_bounds__(512) void qkv256_kernel(ovg_qkv_params p, int nt_be
     stage_rope_table(p, lds256 + g256::LDS_BYTES, 8);      // older than every stage DMA: retired by the loop's first counted wait, visible after its barriers
     g256::mainloop<T, false>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds256, acc);
     qk_epilogue<T, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, rope_tab, rope_tab + 128 * 16);
+  }
+}
+
+// Persistent forms (OVG_TILE_256P): gridDim.x = min(tiles, CUs) workgroups, workgroup w takes the logical tiles
+// xcd_remap(w) + i * gridDim.x, i = 0, 1, ... (an XCD still works on runs of consecutive logical ids = neighbouring tiles of the
+// grouped order, so the operand panels it streams stay in its L2), through g256::mainloop_stream.
+template <typename T, int EPI, bool OUT_F32>
+__global__ __launch_bounds__(512) void linear256p_kernel(ovg_linear_params p, int ntiles_n, int total) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds256[];
+  const int M = (int)p.M, N = (int)p.N, K = (int)p.K;
+  const int mtiles = (M + g256::BM2 - 1) / g256::BM2;
+  const int G = (int)gridDim.x;
+  const int wave = threadIdx.x >> 6;
+  const T* X = static_cast<const T*>(p.x);
+  const T* W = static_cast<const T*>(p.w);
+  int lid = xcd_remap(blockIdx.x, G);
+  int tm, tn;
+  tile_coords(lid, mtiles, ntiles_n, tm, tn);
+  g256::TileSrc cur = g256::tile_sources<T>(X, p.ldx, W, p.ldw, M, N, tm * g256::BM2, tn * g256::BN2);
+  bool first = true;
+  for (; lid < total; lid += G) {
+    const int m0 = tm * g256::BM2, n0 = tn * g256::BN2;
+    const bool has_next = lid + G < total;
+    g256::TileSrc nxt = cur;
+    if (has_next) {
+      tile_coords(lid + G, mtiles, ntiles_n, tm, tn);
+      nxt = g256::tile_sources<T>(X, p.ldx, W, p.ldw, M, N, tm * g256::BM2, tn * g256::BN2);
+    }
+    f32x4 acc[4][8];
+    g256::mainloop_stream<T, false>(cur, nxt, first, has_next, K, lds256, acc);
+    linear_epilogue<T, EPI, OUT_F32, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64);
+    cur = nxt;
+    first = false;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void qkv256p_kernel(ovg_qkv_params p, int nt_begin, int nt_count, int total) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds256[];   // ring (g256::LDS_BYTES) + RoPE table (ROPE_LDS_BYTES)
+  constexpr int N = 3 * OVG_C, K = OVG_C;
+  const int M = (int)p.M;
+  const int mtiles = (M + g256::BM2 - 1) / g256::BM2;
+  const int G = (int)gridDim.x;
+  const int wave = threadIdx.x >> 6;
+  const T* X = static_cast<const T*>(p.x);
+  const T* W = static_cast<const T*>(p.w);
+  float* rope_tab = reinterpret_cast<float*>(lds256 + g256::LDS_BYTES);
+  stage_rope_table(p, lds256 + g256::LDS_BYTES, 8);        // older than every stage DMA: retired by the first counted wait, visible after its barrier
+  int lid = xcd_remap(blockIdx.x, G);
+  int tm, tn;
+  tile_coords(lid, mtiles, nt_count, tm, tn);
+  g256::TileSrc cur = g256::tile_sources<T>(X, p.ldx, W, (int64_t)K, M, N, tm * g256::BM2, (nt_begin + tn) * g256::BN2);
+  bool first = true;
+  for (; lid < total; lid += G) {
+    const int m0 = tm * g256::BM2, n0 = (nt_begin + tn) * g256::BN2;
+    const bool has_next = lid + G < total;
+    g256::TileSrc nxt = cur;
+    if (has_next) {
+      tile_coords(lid + G, mtiles, nt_count, tm, tn);
+      nxt = g256::tile_sources<T>(X, p.ldx, W, (int64_t)K, M, N, tm * g256::BM2, (nt_begin + tn) * g256::BN2);
+    }
+    f32x4 acc[4][8];
+    if (n0 >= 2 * OVG_C) {                                 // V^T tile (workgroup-uniform): transposed accumulators
+      g256::mainloop_stream<T, true>(cur, nxt, first, has_next, K, lds256, acc);
+      v_epilogue<T, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64);
+    } else {
+      g256::mainloop_stream<T, false>(cur, nxt, first, has_next, K, lds256, acc);
+      qk_epilogue<T, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, rope_tab, rope_tab + 128 * 16);
+    }
+    cur = nxt;
+    first = false;
   }
 }
 
@@ -708,12 +701,40 @@ int launch_linear256_one(const ovg_linear_params& p, hipStream_t st) {
   OVG_CHECK_LAUNCH();
   return OVG_OK;
 }
+int persistent_grid(int total) {
+  static const int cus = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    return v;
+  }();
+  return total < cus ? total : cus;
+}
+template <typename T, int EPI, bool OUT_F32>
+int launch_linear256p_one(const ovg_linear_params& p, hipStream_t st) {
+  const int ok = allow_big_lds(linear256p_kernel<T, EPI, OUT_F32>);
+  if (ok != OVG_OK) return ok;
+  const int mt = (int)((p.M + g256::BM2 - 1) / g256::BM2), nt = (int)(p.N / g256::BN2);
+  const int ntg = nt | (TILE_GROUP256 << 16);
+  OVG_LAUNCH((linear256p_kernel<T, EPI, OUT_F32>), dim3(persistent_grid(mt * nt)), dim3(512), g256::LDS_BYTES, st, p, ntg, mt * nt);
+  OVG_CHECK_LAUNCH();
+  return OVG_OK;
+}
+template <typename T>
+int launch_linear256p(const ovg_linear_params& p, hipStream_t st) {
+  switch (p.epilogue) {
+    case OVG_EPI_STORE: return p.out_f32 ? launch_linear256p_one<T, OVG_EPI_STORE, true>(p, st) : launch_linear256p_one<T, OVG_EPI_STORE, false>(p, st);
+    case OVG_EPI_GELU: return launch_linear256p_one<T, OVG_EPI_GELU, false>(p, st);
+    case OVG_EPI_RES: return launch_linear256p_one<T, OVG_EPI_RES, true>(p, st);
+    case OVG_EPI_PATCH: return launch_linear256p_one<T, OVG_EPI_PATCH, true>(p, st);
+    default: return OVG_E_ARG;
+  }
+}
 template <typename T>
 int launch_linear256(const ovg_linear_params& p, hipStream_t st, bool xp) {
   switch (p.epilogue) {
     case OVG_EPI_STORE: return p.out_f32 ? launch_linear256_one<T, OVG_EPI_STORE, true>(p, st) : launch_linear256_one<T, OVG_EPI_STORE, false>(p, st);
     case OVG_EPI_GELU: return xp ? launch_linear256_one<T, OVG_EPI_GELU, false, 1>(p, st) : launch_linear256_one<T, OVG_EPI_GELU, false>(p, st);
-    case OVG_EPI_RES: return xp ? launch_linear256_one<T, OVG_EPI_RES, true, 1>(p, st) : launch_linear256_one<T, OVG_EPI_RES, true>(p, st);
+    case OVG_EPI_RES: return launch_linear256_one<T, OVG_EPI_RES, true>(p, st);
     case OVG_EPI_PATCH: return launch_linear256_one<T, OVG_EPI_PATCH, true>(p, st);
     default: return OVG_E_ARG;
   }
@@ -733,6 +754,7 @@ int choose_256(int tile, bool sixteen_bit, int64_t M, int64_t N, int64_t K, bool
   const bool legal = sixteen_bit && N % g256::BN2 == 0 && K % 32 == 0;
   if (tile == OVG_TILE_128) return 0;
   if (tile == OVG_TILE_256 || tile == OVG_TILE_256X) return legal ? 1 : -1;
+  if (tile == OVG_TILE_256P) return (legal && K % 128 == 0 && K >= 128) ? 2 : -1;   // the stream needs whole ring turns per tile (nk % 4 == 0)
   if (tile != OVG_TILE_AUTO) return -1;
   if (!legal || !light_epilogue_or_long_k || M < 20000) return 0;
   return 1;
@@ -743,6 +765,7 @@ int launch_linear(const ovg_linear_params& p, hipStream_t st) {
   const int big = choose_256(p.tile, sizeof(T) == 2, p.M, p.N, p.K, p.epilogue != OVG_EPI_RES || p.K >= 2048);
   if (big < 0) return OVG_E_ARG;
   if constexpr (sizeof(T) == 2) {
+    if (big == 2) return launch_linear256p<T>(p, st);
     if (big) return launch_linear256<T>(p, st, p.tile == OVG_TILE_256X);
   }
   return launch_linear128<T>(p, st);
@@ -799,6 +822,20 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
     const int ntc = p->part == 0 ? all_t : (p->part == 1 ? all_t - q_t : q_t);
     const dim3 grid2((unsigned)(((p->M + g256::BM2 - 1) / g256::BM2) * ntc));
     const int ntg2 = ntc | (TILE_GROUP256 << 16);
+    if (big == 2) {                                         // persistent stream form
+      const int total = (int)grid2.x;
+      if (p->dtype == OVG_BF16) {
+        const int ok = allow_big_lds(qkv256p_kernel<bf16_t>, g256::LDS_BYTES + ROPE_LDS_BYTES);
+        if (ok != OVG_OK) return ok;
+        OVG_LAUNCH((qkv256p_kernel<bf16_t>), dim3(persistent_grid(total)), dim3(512), g256::LDS_BYTES + ROPE_LDS_BYTES, st, *p, ntb, ntg2, total);
+      } else {
+        const int ok = allow_big_lds(qkv256p_kernel<f16_t>, g256::LDS_BYTES + ROPE_LDS_BYTES);
+        if (ok != OVG_OK) return ok;
+        OVG_LAUNCH((qkv256p_kernel<f16_t>), dim3(persistent_grid(total)), dim3(512), g256::LDS_BYTES + ROPE_LDS_BYTES, st, *p, ntb, ntg2, total);
+      }
+      OVG_CHECK_LAUNCH();
+      return OVG_OK;
+    }
     if (p->dtype == OVG_BF16) {
       const int ok = allow_big_lds(qkv256_kernel<bf16_t>, g256::LDS_BYTES + ROPE_LDS_BYTES);
       if (ok != OVG_OK) return ok;

@@ -356,7 +356,8 @@ def test_oracle_parity_stress_128_views_f16_partial_aux_depth1():
 def test_fp16_mode_with_outlier_activations():
     """fp16 range safety (SURVEY section 7 hard part; DINOv2-reg high-norm tokens, layers/vision_transformer.py:214-271):
     weights that reproduce the massive-activation pattern -- a few residual channels at |x| ~ 3e2..1e3 from the first DINOv2
-    block on, register tokens two orders above the patch tokens, hidden units of the first frame block at ~4e3 -- through the
+    block on AND from the first frame block on (the latter reach the outputs), register tokens two orders above the patch
+    tokens, hidden units of the first frame block at ~4e3 -- through the
     f16 mode at 8 views. The f32 mode of the same library (oracle-proven) is the reference: f16 must stay finite and within
     2x the error of the bf16 mode (whose exponent range cannot overflow) on every layer."""
     sd = {k: v.clone() for k, v in common.reduced_state_dict(2, 2).items()}
@@ -368,6 +369,10 @@ def test_fp16_mode_with_outlier_activations():
     units = torch.randperm(4096, generator=g)[:8]
     sd["aggregator.frame_blocks.0.mlp.fc1.bias"][units] = 4000.0
     sd["aggregator.frame_blocks.0.mlp.fc2.weight"][:, units] *= 1e-2      # keep their contribution O(10): the point is the f16 STORE of 4e3
+    # the DINOv2 outliers above are renormalised by the backbone's final LayerNorm; these live in the AA trunk's residual stream
+    # (LayerScale gamma ~ 1 in the synthetic weights) and therefore in every later LayerNorm / GEMM input and in the outputs
+    hot2 = torch.randperm(1024, generator=g)[:4]
+    sd["aggregator.frame_blocks.0.mlp.fc2.bias"][hot2] = torch.tensor([400.0, -700.0, 1000.0, -300.0])
     S, dgi, cgi = 8, [1, 6], [0, 4]
     outs = {}
     for dtype in (torch.float32, torch.bfloat16, torch.float16):

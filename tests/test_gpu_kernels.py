@@ -73,10 +73,17 @@ def test_gemm256_kernels_every_epilogue_ragged_m():
     _assert_clean()
 
 
-def test_gemm256_r03_epilogue_forms():
-    """OVG_TILE_256X: the residual epilogue through LDS-DMA (full tiles; ragged tiles and the injection variant fall back) and
-    the polynomial GELU, every epilogue / ragged M / in-place residual again."""
-    st.test_gemm256(False, tile=L.TILE_256X, auto_is=False)
+def test_gemm256_r02_gelu_form_behind_the_knob():
+    """OVG_TILE_256X keeps the r02 erf_as GELU selectable for A/B runs (the default 16-bit GELU is the polynomial form)."""
+    st.test_gemm256(True, tile=L.TILE_256X, auto_is=False)
+    _assert_clean()
+
+
+def test_gemm256_persistent_stream_every_epilogue_ragged_m():
+    """OVG_TILE_256P: one workgroup per CU walking a tile list, consecutive tiles' k-stages one stream through the LDS ring --
+    every epilogue / all three QKV parts / ragged M / in-place residual / K = 640 (PATCH), from 4 tiles (each workgroup one tile,
+    no successor) to 5504 tiles (21.5 per workgroup)."""
+    st.test_gemm256(False, tile=L.TILE_256P, auto_is=False)
     _assert_clean()
 
 
