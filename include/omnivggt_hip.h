@@ -96,8 +96,9 @@ enum { OVG_EPI_STORE = 0, OVG_EPI_GELU = 1, OVG_EPI_RES = 2, OVG_EPI_PATCH = 3 }
 /* workgroup tile of the GEMM kernels: 128 x 128 (4 waves, register-staged, up to 3 workgroups per CU) or 256 x 256 (8 waves,
  * LDS-DMA ring with ping-pong wave groups, 1 workgroup per CU, 16-bit dtypes); AUTO picks by shape (ovg_gemm.hip: choose_256) */
 enum { OVG_TILE_AUTO = 0, OVG_TILE_128 = 1, OVG_TILE_256 = 2,
-       OVG_TILE_256X = 3, /* A/B knob: the 256 x 256 kernels with the r02 erf_as GELU instead of the polynomial one (ovg_gemm.hip) */
-       OVG_TILE_256P = 4  /* 256 x 256 PERSISTENT: one workgroup per CU walks a tile list, consecutive tiles' k-stages one stream through the LDS ring (K % 128 == 0) */ };
+       /* A/B flag, OR-ed onto any of the three: the same kernels with the r02 epilogue forms (erf_as GELU; per-lane 8- / 16-byte stores in
+        * the accumulator layout instead of whole lines staged through the idle LDS -- ovg_gemm.hip) */
+       OVG_TILE_R02_EPILOGUE = 16, OVG_TILE_128X = 17, OVG_TILE_256X = 18 };
 typedef struct {
   const void* x; int64_t ldx;
   const void* w; int64_t ldw;

@@ -414,10 +414,11 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
     const int64_t full = units / slots;
     const double frac = (double)units / slots - (double)full;
     const int64_t rows_a = full * slots / p.BH * pl.bq;
-    // measured (profiles/r03_attention_tail256_ab.txt): 10 views (1.69 rounds) +4.5 %, 8 views (1.34 rounds) -4 % -- a third-full second round of
-    // lone workgroups (one per CU, the whole CU's LDS bandwidth and issue slots to itself) already runs fast; from half a round on the split wins
-    const double lo = p.variant == 72 ? 0.05 : 0.5;
-    if (full >= 1 && frac > lo && frac < 0.85 && rows_a > 0 && rows_a < p.nq) {
+    // measured (profiles/r03_attention_tail256_ab.txt, r03_attention_tail256_sweep.txt): 9 / 10 views (1.53 / 1.69 rounds) +6.3 / +4.5 %; 8 views
+    // (1.34 rounds) -4 % -- a third-full second round of lone workgroups (one per CU, the whole CU's LDS bandwidth and issue slots to itself)
+    // already runs fast; 13 / 14 views (2.19 / 2.38 rounds) +1.8 / -3 %. So: exactly one full round and at least half a round of tail.
+    const bool want = p.variant == 72 ? (full >= 1 && frac > 0.05) : (full == 1 && frac > 0.5);
+    if (want && frac < 0.85 && rows_a > 0 && rows_a < p.nq) {
       const int rc = launch_attn16<T, 4, 4, 0, 2, false, 3>(p, pl, st, 0, rows_a);
       return rc != OVG_OK ? rc : launch_attn16<T, 2, 4, 0, 2, false, 3>(p, pl, st, rows_a, p.nq);
     }

@@ -182,7 +182,7 @@ OVG_DEV void gemm_mainloop(const T* __restrict__ X, int64_t ldx, const T* __rest
 // Now: the per-column vectors (bias, gamma) are loaded ONCE per wave, the row loop bodies are branch-free (row
 // indices clamped for the loads, only the store is predicated), so the four residual / table loads of a row block
 // -- and, registers permitting, the next row block's -- are in flight together.
-template <typename T, int EPI, bool OUT_F32, int MT, bool INJECT, int XP = 0>   // XP = 1 (OVG_TILE_256X, A/B knob): the r02 erf_as GELU instead of the polynomial one
+template <typename T, int EPI, bool OUT_F32, int MT, bool INJECT, int XP = 0>   // XP = 1 (OVG_TILE_R02_EPILOGUE, A/B flag): the r02 erf_as GELU instead of the polynomial one
 OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int n_w0) {
   const int M = (int)p.M, N = (int)p.N;
   const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
@@ -259,7 +259,7 @@ OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)
     for (int nt = 0; nt < 4; ++nt) {
       v[nt] = acc[nt][mt] + bias[nt];
       if constexpr (EPI == OVG_EPI_GELU) {
-        if constexpr (XP || sizeof(T) == 4) {        // f32 parity mode: libm erff; XP (A/B knob OVG_TILE_256X): the r02 erf_as form; else the polynomial form below
+        if constexpr (XP || sizeof(T) == 4) {        // f32 parity mode: libm erff; XP (A/B flag OVG_TILE_R02_EPILOGUE): the r02 erf_as form; else the polynomial form below
           v[nt][0] = gelu_erf<T>(v[nt][0]); v[nt][1] = gelu_erf<T>(v[nt][1]); v[nt][2] = gelu_erf<T>(v[nt][2]); v[nt][3] = gelu_erf<T>(v[nt][3]);
         }
         if constexpr (std::is_same<T, f16_t>::value && XP) {
@@ -297,6 +297,118 @@ OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Full-line stores through the idle LDS ring (256 x 256 kernels, r03).
+// In the MFMA accumulator layout a lane owns 4 consecutive columns of ONE row, so a wave-wide store instruction of the register
+// epilogues touches 16 rows x 32 B (16-bit outputs: 32 global_store_dwordx2 per lane, quarter lines) or 16 rows x 64 B (f32). The
+// two-point fit over K (profiles/r02_gemm_persistent_ab.txt: 111.5 us for 128 k-stages, 211.4 us for 256) puts ~11.6 us of FIXED cost
+// under every 256 x 256 tile, a third of a K = 1024 tile, and the persistent-stream experiment of this round
+// (profiles/r03_gemm_persistent_ab.txt: dispatch, set-up and pipeline fill removed, +-2 %) showed that it is not the launch side:
+// it is the store tail -- the guide prices a row-per-lane 8-byte store epilogue at ~7 B/cycle/CU, issue-bound, and halves it with
+// 16-byte stores (T21). After the main loop the 128 KB ring is idle and every wave owns 16 KB of it = exactly its 64 x 128 block in
+// 16 bits (two passes of 64 rows for f32): the lanes write their values into a row-major image (16-byte chunks XOR-swizzled with the
+// row so the writes spread over the banks), and read it back ROW-wise -- 8 (16-bit) or 16 (f32) lanes per row, 16 bytes each -- so one
+// store instruction writes 8 whole 128-byte lines (16-bit) or 4 x 256 B (f32), and the residual is LOADED in the same shape.
+// Same wave writes and reads (LDS operations of a wave execute in order): no barrier.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T> OVG_DEV void stage16_put4(unsigned char* img, int row, int col, float a, float b, float c, float d) {   // image rows of 64 T (128 B)
+  const int chunk = col >> 3, half = (col >> 2) & 1;
+  store4<T>(reinterpret_cast<T*>(img + row * 128 + ((chunk ^ (row & 7)) << 4) + half * 8), a, b, c, d);
+}
+OVG_DEV u32x4 stage16_get(const unsigned char* img, int row, int chunk) {
+  return *reinterpret_cast<const u32x4*>(img + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+OVG_DEV void stage32_put4(unsigned char* img, int row, int col, const f32x4 v) {                                            // image rows of 64 f32 (256 B)
+  *reinterpret_cast<f32x4*>(img + row * 256 + (((col >> 2) ^ (row & 15)) << 4)) = v;
+}
+OVG_DEV f32x4 stage32_get(const unsigned char* img, int row, int chunk) {
+  return *reinterpret_cast<const f32x4*>(img + row * 256 + ((chunk ^ (row & 15)) << 4));
+}
+
+// STORE / GELU with 16-bit output and RES (f32 output, no injection row among the wave's rows -- the caller checks) on a wave's
+// 64 (n) x 16 MT (m) block; `img` = the wave's private 2 KB x MT of idle LDS (16 KB of the ring in the 256 x 256 kernels, 8 KB of the
+// two stage buffers in the 128 x 128 kernels): the whole block in 16 bits, half of it per pass in f32.
+template <typename T, int EPI, int MT>
+OVG_DEV void linear_epilogue_staged(const ovg_linear_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int n_w0, unsigned char* img) {
+  const int M = (int)p.M;
+  const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
+  const int ncol = n_w0 + 4 * g;
+  f32x4 bias[4];
+  if (p.bias != nullptr) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bias[nt] = *reinterpret_cast<const f32x4*>(p.bias + ncol + nt * 16);
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bias[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if constexpr (EPI == OVG_EPI_RES) {
+    constexpr int HR = 8 * MT, HB = MT / 2, NI = HR / 4;        // rows per pass, 16-row blocks per pass, read-back instructions per pass
+    f32x4 gam[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      gam[nt] = *reinterpret_cast<const f32x4*>(p.gamma + ncol + nt * 16);
+      bias[nt] = gam[nt] * bias[nt];
+    }
+    const int prow = lane >> 4, pch = lane & 15;               // read-back shape: 4 rows x 16 chunks of 16 B (4 x 256 B) per instruction
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      // residual rows of this pass, in the read-back shape, requested before the image is written (independent of it)
+      f32x4 res[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        int m = m_w0 + half * HR + i * 4 + prow;
+        m = m < M ? m : M - 1;
+        res[i] = *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldres + n_w0 + pch * 4);
+      }
+#pragma unroll
+      for (int ml = 0; ml < HB; ++ml)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) stage32_put4(img, ml * 16 + lr, nt * 16 + 4 * g, gam[nt] * acc[nt][half * HB + ml] + bias[nt]);
+#pragma unroll
+      for (int i0 = 0; i0 < NI; i0 += 4) {                      // read-backs in batches of four: four LDS latencies overlap instead of NI in a row
+        f32x4 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = stage32_get(img, (i0 + j) * 4 + prow, pch);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int m = m_w0 + half * HR + (i0 + j) * 4 + prow;
+          if (m < M) *reinterpret_cast<f32x4*>(static_cast<float*>(p.y) + (int64_t)m * p.ldy + n_w0 + pch * 4) = res[i0 + j] + t[j];
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      f32x4 v[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) v[nt] = acc[nt][mt] + bias[nt];
+      if constexpr (EPI == OVG_EPI_GELU) {
+        gelu_poly16(v);
+        if constexpr (std::is_same<T, f16_t>::value) {          // f16 range guard (see linear_epilogue_impl)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[nt][r] = fminf(v[nt][r], 65504.0f);
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) stage16_put4<T>(img, mt * 16 + lr, nt * 16 + 4 * g, v[nt][0], v[nt][1], v[nt][2], v[nt][3]);
+    }
+    const int prow = lane >> 3, pch = lane & 7;                 // read-back shape: 8 rows x 8 chunks of 16 B = 8 whole lines per instruction
+#pragma unroll
+    for (int i0 = 0; i0 < 2 * MT; i0 += 4) {
+      u32x4 t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] = stage16_get(img, (i0 + j) * 8 + prow, pch);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = m_w0 + (i0 + j) * 8 + prow;
+        if (m < M) *reinterpret_cast<u32x4*>(static_cast<T*>(p.y) + (int64_t)m * p.ldy + n_w0 + pch * 8) = t[j];
+      }
+    }
+  }
+}
+
 template <typename T, int EPI, bool OUT_F32, int MT, int XP = 0>
 OVG_DEV void linear_epilogue(const ovg_linear_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int n_w0) {
   if constexpr (EPI == OVG_EPI_RES) {
@@ -305,7 +417,28 @@ OVG_DEV void linear_epilogue(const ovg_linear_params& p, const f32x4 (&acc)[4][M
   linear_epilogue_impl<T, EPI, OUT_F32, MT, false, XP>(p, acc, m_w0, n_w0);
 }
 
-template <typename T, int EPI, bool OUT_F32>
+// Which epilogue a wave of a 16-bit kernel takes (wave-uniform): the staged one unless the caller pinned the r02 register form (XP), the output
+// cannot take 16-byte stores, or -- residual form -- one of the wave's rows is a camera-injection row (m % inj_period == 0: 1 row in 1374).
+template <typename T, int EPI, bool OUT_F32, int MT, int XP>
+OVG_DEV void linear_epilogue_auto(const ovg_linear_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int n_w0, unsigned char* img) {
+  if constexpr (!XP && sizeof(T) == 2) {
+    if constexpr ((EPI == OVG_EPI_STORE || EPI == OVG_EPI_GELU) && !OUT_F32) {
+      if (((p.ldy * (int64_t)sizeof(T)) & 15) == 0) { linear_epilogue_staged<T, EPI, MT>(p, acc, m_w0, n_w0, img); return; }
+    }
+    if constexpr (EPI == OVG_EPI_RES) {
+      bool inj_here = false;
+      if (p.inject != nullptr) {
+        const int rem = m_w0 % (int)p.inj_period;
+        inj_here = rem == 0 || (int)p.inj_period - rem < 16 * MT;
+      }
+      if (!inj_here) { linear_epilogue_staged<T, EPI, MT>(p, acc, m_w0, n_w0, img); return; }
+    }
+  }
+  linear_epilogue<T, EPI, OUT_F32, MT, XP>(p, acc, m_w0, n_w0);
+}
+
+
+template <typename T, int EPI, bool OUT_F32, int XP = 0>
 __global__ __launch_bounds__(256, 2) void linear_kernel(ovg_linear_params p, int ntiles_n) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128];
   const int M = (int)p.M, N = (int)p.N, K = (int)p.K;
@@ -314,8 +447,9 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(ovg_linear_params p, int
   const int m0 = tm * BM, n0 = tn * BN;
   f32x4 acc[4][4];
   gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds, acc);
-  const int wave = threadIdx.x >> 6;
-  linear_epilogue<T, EPI, OUT_F32, 4>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // gemm_mainloop ends behind a __syncthreads: both stage buffers (32 KB) are idle, wave w owns 8 KB of them
+  linear_epilogue_auto<T, EPI, OUT_F32, 4, XP>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64, lds + wave * 8192);
 }
 
 // ---------------------------------------------------------------------------
@@ -331,7 +465,9 @@ template <typename T, int MT, bool NORM, bool ROPE>
 OVG_DEV void qk_rows(const f32x4 (&acc)[4][MT], const float (&bias)[16], const float* __restrict__ nw_p, const float* __restrict__ nb_p,
                      const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, T* __restrict__ out, const int64_t npad,
                      const int m_w0, const int M, const int seq, const int h, const int tokens_per_view, const int n_special,
-                     const int grid_w, const float qk_eps, const float scale) {
+                     const int grid_w, const float qk_eps, const float scale, unsigned char* img = nullptr) {
+  // img != nullptr (16-bit modes): the wave's 2 KB x MT of idle LDS -- the 64-wide head rows (128 B = one line per token) are written into
+  // a row-major image and stored as whole lines afterwards (see linear_epilogue_staged)
   const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
   const FastDiv div_seq(seq), div_tpv(ROPE ? tokens_per_view : 1), div_gw(ROPE ? grid_w : 1);
   float nw[16], nb[16];
@@ -398,17 +534,42 @@ OVG_DEV void qk_rows(const f32x4 (&acc)[4][MT], const float (&bias)[16], const f
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] *= scale;          // 1.0 for k (exact), q_scale for q
+    if constexpr (sizeof(T) == 2) {
+      if (img != nullptr) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) stage16_put4<T>(img, mt * 16 + lr, nt * 16 + 4 * g, v[nt * 4], v[nt * 4 + 1], v[nt * 4 + 2], v[nt * 4 + 3]);
+        continue;
+      }
+    }
     if (valid) {
       T* dst = out + (((int64_t)bidx * OVG_H + h) * npad + n) * OVG_D + 4 * g;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) store4<T>(dst + nt * 16, v[nt * 4], v[nt * 4 + 1], v[nt * 4 + 2], v[nt * 4 + 3]);
     }
   }
+  if constexpr (sizeof(T) == 2) {
+    if (img != nullptr) {
+      const int prow = lane >> 3, pch = lane & 7;               // 8 tokens x 8 chunks of 16 B per instruction: 8 whole 128-byte head rows
+#pragma unroll
+      for (int i0 = 0; i0 < 2 * MT; i0 += 4) {
+        u32x4 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = stage16_get(img, (i0 + j) * 8 + prow, pch);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int m = m_w0 + (i0 + j) * 8 + prow;
+          int bidx, n;
+          div_seq.divmod(m < M ? m : M - 1, bidx, n);
+          if (m < M) *reinterpret_cast<u32x4*>(out + (((int64_t)bidx * OVG_H + h) * npad + n) * OVG_D + pch * 8) = t[j];
+        }
+      }
+    }
+  }
 }
 
 template <typename T, int MT>
 OVG_DEV void qk_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int ncol0_,
-                         const float* rope_c, const float* rope_s) {
+                         const float* rope_c, const float* rope_s, unsigned char* img = nullptr) {
   const int ncol0 = __builtin_amdgcn_readfirstlane(ncol0_);   // wave-uniform: keep the q/k/v dispatch scalar
   const int M = (int)p.M;
   const int lane = threadIdx.x & 63, g = lane >> 4;
@@ -430,7 +591,7 @@ OVG_DEV void qk_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], con
     const float scale = which == 0 ? p.q_scale : 1.0f;
     const int tpv = (int)p.tokens_per_view;
 #define OVG_QK_ROWS(NORM, ROPE) qk_rows<T, MT, NORM, ROPE>(acc, bias, nw_p, nb_p, rope_c, rope_s, out, npad, m_w0, M, seq, h, \
-                                                             tpv, p.n_special, p.grid_w, p.qk_eps, scale)
+                                                             tpv, p.n_special, p.grid_w, p.qk_eps, scale, img)
     if (p.qk_norm) { if (p.rope) OVG_QK_ROWS(true, true); else OVG_QK_ROWS(true, false); }
     else { if (p.rope) OVG_QK_ROWS(false, true); else OVG_QK_ROWS(false, false); }
 #undef OVG_QK_ROWS
@@ -532,7 +693,10 @@ __global__ __launch_bounds__(256, 3) void qkv_kernel(ovg_qkv_params p, int nt_be
     // 3 workgroups per CU hide the RoPE-table round trips here: the table is read from global memory (L1 / L2 hits); staging it
     // in LDS cost more than it saved on these small tiles (the DMA sits in front of the register-staged loop's first loads)
     gemm_mainloop<T, false>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
-    qk_epilogue<T, 4>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64, p.rope_cos, p.rope_sin);
+    // behind the main loop's last __syncthreads the two stage buffers are idle: wave w stages its head rows through 8 KB of them
+    // (the OVG_TILE_R02_EPILOGUE flag keeps the r02 per-lane 8-byte stores: A/B)
+    unsigned char* img = (sizeof(T) == 2 && !(p.tile & OVG_TILE_R02_EPILOGUE)) ? lds + __builtin_amdgcn_readfirstlane(wave) * 8192 : nullptr;
+    qk_epilogue<T, 4>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64, p.rope_cos, p.rope_sin, img);
   }
 }
 
@@ -548,8 +712,9 @@ __global__ __launch_bounds__(512) void linear256_kernel(ovg_linear_params p, int
   const int m0 = tm * g256::BM2, n0 = tn * g256::BN2;
   f32x4 acc[4][8];
   g256::mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds256, acc);
-  const int wave = threadIdx.x >> 6;
-  linear_epilogue<T, EPI, OUT_F32, 8, XP>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // the ring is idle: mainloop() returns behind its last barrier, every DMA waited for; wave w owns 16 KB of it
+  linear_epilogue_auto<T, EPI, OUT_F32, 8, XP>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, lds256 + wave * 16384);
 }
 
 template <typename T>
@@ -569,78 +734,9 @@ __global__ __launch_bounds__(512) void qkv256_kernel(ovg_qkv_params p, int nt_be
     float* rope_tab = reinterpret_cast<float*>(lds256 + g256::LDS_BYTES);
     stage_rope_table(p, lds256 + g256::LDS_BYTES, 8);      // older than every stage DMA: retired by the loop's first counted wait, visible after its barriers
     g256::mainloop<T, false>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds256, acc);
-    qk_epilogue<T, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, rope_tab, rope_tab + 128 * 16);
-  }
-}
-
-// Persistent forms (OVG_TILE_256P): gridDim.x = min(tiles, CUs) workgroups, workgroup w takes the logical tiles
-// xcd_remap(w) + i * gridDim.x, i = 0, 1, ... (an XCD still works on runs of consecutive logical ids = neighbouring tiles of the
-// grouped order, so the operand panels it streams stay in its L2), through g256::mainloop_stream.
-template <typename T, int EPI, bool OUT_F32>
-__global__ __launch_bounds__(512) void linear256p_kernel(ovg_linear_params p, int ntiles_n, int total) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds256[];
-  const int M = (int)p.M, N = (int)p.N, K = (int)p.K;
-  const int mtiles = (M + g256::BM2 - 1) / g256::BM2;
-  const int G = (int)gridDim.x;
-  const int wave = threadIdx.x >> 6;
-  const T* X = static_cast<const T*>(p.x);
-  const T* W = static_cast<const T*>(p.w);
-  int lid = xcd_remap(blockIdx.x, G);
-  int tm, tn;
-  tile_coords(lid, mtiles, ntiles_n, tm, tn);
-  g256::TileSrc cur = g256::tile_sources<T>(X, p.ldx, W, p.ldw, M, N, tm * g256::BM2, tn * g256::BN2);
-  bool first = true;
-  for (; lid < total; lid += G) {
-    const int m0 = tm * g256::BM2, n0 = tn * g256::BN2;
-    const bool has_next = lid + G < total;
-    g256::TileSrc nxt = cur;
-    if (has_next) {
-      tile_coords(lid + G, mtiles, ntiles_n, tm, tn);
-      nxt = g256::tile_sources<T>(X, p.ldx, W, p.ldw, M, N, tm * g256::BM2, tn * g256::BN2);
-    }
-    f32x4 acc[4][8];
-    g256::mainloop_stream<T, false>(cur, nxt, first, has_next, K, lds256, acc);
-    linear_epilogue<T, EPI, OUT_F32, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64);
-    cur = nxt;
-    first = false;
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(512) void qkv256p_kernel(ovg_qkv_params p, int nt_begin, int nt_count, int total) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds256[];   // ring (g256::LDS_BYTES) + RoPE table (ROPE_LDS_BYTES)
-  constexpr int N = 3 * OVG_C, K = OVG_C;
-  const int M = (int)p.M;
-  const int mtiles = (M + g256::BM2 - 1) / g256::BM2;
-  const int G = (int)gridDim.x;
-  const int wave = threadIdx.x >> 6;
-  const T* X = static_cast<const T*>(p.x);
-  const T* W = static_cast<const T*>(p.w);
-  float* rope_tab = reinterpret_cast<float*>(lds256 + g256::LDS_BYTES);
-  stage_rope_table(p, lds256 + g256::LDS_BYTES, 8);        // older than every stage DMA: retired by the first counted wait, visible after its barrier
-  int lid = xcd_remap(blockIdx.x, G);
-  int tm, tn;
-  tile_coords(lid, mtiles, nt_count, tm, tn);
-  g256::TileSrc cur = g256::tile_sources<T>(X, p.ldx, W, (int64_t)K, M, N, tm * g256::BM2, (nt_begin + tn) * g256::BN2);
-  bool first = true;
-  for (; lid < total; lid += G) {
-    const int m0 = tm * g256::BM2, n0 = (nt_begin + tn) * g256::BN2;
-    const bool has_next = lid + G < total;
-    g256::TileSrc nxt = cur;
-    if (has_next) {
-      tile_coords(lid + G, mtiles, nt_count, tm, tn);
-      nxt = g256::tile_sources<T>(X, p.ldx, W, (int64_t)K, M, N, tm * g256::BM2, (nt_begin + tn) * g256::BN2);
-    }
-    f32x4 acc[4][8];
-    if (n0 >= 2 * OVG_C) {                                 // V^T tile (workgroup-uniform): transposed accumulators
-      g256::mainloop_stream<T, true>(cur, nxt, first, has_next, K, lds256, acc);
-      v_epilogue<T, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64);
-    } else {
-      g256::mainloop_stream<T, false>(cur, nxt, first, has_next, K, lds256, acc);
-      qk_epilogue<T, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, rope_tab, rope_tab + 128 * 16);
-    }
-    cur = nxt;
-    first = false;
+    // the OVG_TILE_R02_EPILOGUE flag keeps the r02 per-lane 8-byte stores (A/B); otherwise whole head rows through the idle ring
+    unsigned char* img = (p.tile & OVG_TILE_R02_EPILOGUE) ? nullptr : lds256 + __builtin_amdgcn_readfirstlane(wave) * 16384;
+    qk_epilogue<T, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, rope_tab, rope_tab + 128 * 16, img);
   }
 }
 
@@ -667,29 +763,36 @@ constexpr int TILE_GROUP = 8, TILE_GROUP256 = 4;
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <typename T>
-int launch_linear128(const ovg_linear_params& p, hipStream_t st) {
+template <typename T, int XP>
+int launch_linear128_xp(const ovg_linear_params& p, hipStream_t st) {
   const int mt = (int)((p.M + BM - 1) / BM), nt = (int)(p.N / BN);
   const dim3 grid(mt * nt), block(256);
   const int ntg = nt | (TILE_GROUP << 16);
   switch (p.epilogue) {
     case OVG_EPI_STORE:
-      if (p.out_f32) OVG_LAUNCH((linear_kernel<T, OVG_EPI_STORE, true>), grid, block, 0, st, p, ntg);
-      else OVG_LAUNCH((linear_kernel<T, OVG_EPI_STORE, false>), grid, block, 0, st, p, ntg);
+      if (p.out_f32) OVG_LAUNCH((linear_kernel<T, OVG_EPI_STORE, true, XP>), grid, block, 0, st, p, ntg);
+      else OVG_LAUNCH((linear_kernel<T, OVG_EPI_STORE, false, XP>), grid, block, 0, st, p, ntg);
       break;
     case OVG_EPI_GELU:
-      OVG_LAUNCH((linear_kernel<T, OVG_EPI_GELU, false>), grid, block, 0, st, p, ntg);
+      OVG_LAUNCH((linear_kernel<T, OVG_EPI_GELU, false, XP>), grid, block, 0, st, p, ntg);
       break;
     case OVG_EPI_RES:
-      OVG_LAUNCH((linear_kernel<T, OVG_EPI_RES, true>), grid, block, 0, st, p, ntg);
+      OVG_LAUNCH((linear_kernel<T, OVG_EPI_RES, true, XP>), grid, block, 0, st, p, ntg);
       break;
     case OVG_EPI_PATCH:
-      OVG_LAUNCH((linear_kernel<T, OVG_EPI_PATCH, true>), grid, block, 0, st, p, ntg);
+      OVG_LAUNCH((linear_kernel<T, OVG_EPI_PATCH, true, XP>), grid, block, 0, st, p, ntg);
       break;
     default: return OVG_E_ARG;
   }
   OVG_CHECK_LAUNCH();
   return OVG_OK;
+}
+template <typename T>
+int launch_linear128(const ovg_linear_params& p, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    if (p.tile & OVG_TILE_R02_EPILOGUE) return launch_linear128_xp<T, 1>(p, st);      // A/B flag: the r02 epilogue forms
+  }
+  return launch_linear128_xp<T, 0>(p, st);
 }
 template <typename T, int EPI, bool OUT_F32, int XP = 0>
 int launch_linear256_one(const ovg_linear_params& p, hipStream_t st) {
@@ -701,40 +804,12 @@ int launch_linear256_one(const ovg_linear_params& p, hipStream_t st) {
   OVG_CHECK_LAUNCH();
   return OVG_OK;
 }
-int persistent_grid(int total) {
-  static const int cus = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    return v;
-  }();
-  return total < cus ? total : cus;
-}
-template <typename T, int EPI, bool OUT_F32>
-int launch_linear256p_one(const ovg_linear_params& p, hipStream_t st) {
-  const int ok = allow_big_lds(linear256p_kernel<T, EPI, OUT_F32>);
-  if (ok != OVG_OK) return ok;
-  const int mt = (int)((p.M + g256::BM2 - 1) / g256::BM2), nt = (int)(p.N / g256::BN2);
-  const int ntg = nt | (TILE_GROUP256 << 16);
-  OVG_LAUNCH((linear256p_kernel<T, EPI, OUT_F32>), dim3(persistent_grid(mt * nt)), dim3(512), g256::LDS_BYTES, st, p, ntg, mt * nt);
-  OVG_CHECK_LAUNCH();
-  return OVG_OK;
-}
-template <typename T>
-int launch_linear256p(const ovg_linear_params& p, hipStream_t st) {
-  switch (p.epilogue) {
-    case OVG_EPI_STORE: return p.out_f32 ? launch_linear256p_one<T, OVG_EPI_STORE, true>(p, st) : launch_linear256p_one<T, OVG_EPI_STORE, false>(p, st);
-    case OVG_EPI_GELU: return launch_linear256p_one<T, OVG_EPI_GELU, false>(p, st);
-    case OVG_EPI_RES: return launch_linear256p_one<T, OVG_EPI_RES, true>(p, st);
-    case OVG_EPI_PATCH: return launch_linear256p_one<T, OVG_EPI_PATCH, true>(p, st);
-    default: return OVG_E_ARG;
-  }
-}
 template <typename T>
 int launch_linear256(const ovg_linear_params& p, hipStream_t st, bool xp) {
   switch (p.epilogue) {
-    case OVG_EPI_STORE: return p.out_f32 ? launch_linear256_one<T, OVG_EPI_STORE, true>(p, st) : launch_linear256_one<T, OVG_EPI_STORE, false>(p, st);
+    case OVG_EPI_STORE: return p.out_f32 ? launch_linear256_one<T, OVG_EPI_STORE, true>(p, st) : (xp ? launch_linear256_one<T, OVG_EPI_STORE, false, 1>(p, st) : launch_linear256_one<T, OVG_EPI_STORE, false>(p, st));
     case OVG_EPI_GELU: return xp ? launch_linear256_one<T, OVG_EPI_GELU, false, 1>(p, st) : launch_linear256_one<T, OVG_EPI_GELU, false>(p, st);
-    case OVG_EPI_RES: return launch_linear256_one<T, OVG_EPI_RES, true>(p, st);
+    case OVG_EPI_RES: return xp ? launch_linear256_one<T, OVG_EPI_RES, true, 1>(p, st) : launch_linear256_one<T, OVG_EPI_RES, true>(p, st);
     case OVG_EPI_PATCH: return launch_linear256_one<T, OVG_EPI_PATCH, true>(p, st);
     default: return OVG_E_ARG;
   }
@@ -750,11 +825,11 @@ int launch_linear256(const ovg_linear_params& p, hipStream_t st, bool xp) {
 // 189.0 frames/s, 16 views + aux 155.5 vs 156.8 (256 x 256) -- so the 256 x 256 kernels are used from M >= 20 000 rows (16 views) on,
 // where they are worth +1 % (16 views) ... +2 % (64 views) on the forward.
 // Returns 1 = use 256^2, 0 = use 128^2, -1 = the caller forced a tile this shape / dtype cannot run.
-int choose_256(int tile, bool sixteen_bit, int64_t M, int64_t N, int64_t K, bool light_epilogue_or_long_k) {
+int choose_256(int tile_arg, bool sixteen_bit, int64_t M, int64_t N, int64_t K, bool light_epilogue_or_long_k) {
+  const int tile = tile_arg & ~OVG_TILE_R02_EPILOGUE;      // the A/B flag does not take part in the tile choice
   const bool legal = sixteen_bit && N % g256::BN2 == 0 && K % 32 == 0;
   if (tile == OVG_TILE_128) return 0;
-  if (tile == OVG_TILE_256 || tile == OVG_TILE_256X) return legal ? 1 : -1;
-  if (tile == OVG_TILE_256P) return (legal && K % 128 == 0 && K >= 128) ? 2 : -1;   // the stream needs whole ring turns per tile (nk % 4 == 0)
+  if (tile == OVG_TILE_256) return legal ? 1 : -1;
   if (tile != OVG_TILE_AUTO) return -1;
   if (!legal || !light_epilogue_or_long_k || M < 20000) return 0;
   return 1;
@@ -765,8 +840,7 @@ int launch_linear(const ovg_linear_params& p, hipStream_t st) {
   const int big = choose_256(p.tile, sizeof(T) == 2, p.M, p.N, p.K, p.epilogue != OVG_EPI_RES || p.K >= 2048);
   if (big < 0) return OVG_E_ARG;
   if constexpr (sizeof(T) == 2) {
-    if (big == 2) return launch_linear256p<T>(p, st);
-    if (big) return launch_linear256<T>(p, st, p.tile == OVG_TILE_256X);
+    if (big) return launch_linear256<T>(p, st, (p.tile & OVG_TILE_R02_EPILOGUE) != 0);
   }
   return launch_linear128<T>(p, st);
 }
@@ -822,20 +896,6 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
     const int ntc = p->part == 0 ? all_t : (p->part == 1 ? all_t - q_t : q_t);
     const dim3 grid2((unsigned)(((p->M + g256::BM2 - 1) / g256::BM2) * ntc));
     const int ntg2 = ntc | (TILE_GROUP256 << 16);
-    if (big == 2) {                                         // persistent stream form
-      const int total = (int)grid2.x;
-      if (p->dtype == OVG_BF16) {
-        const int ok = allow_big_lds(qkv256p_kernel<bf16_t>, g256::LDS_BYTES + ROPE_LDS_BYTES);
-        if (ok != OVG_OK) return ok;
-        OVG_LAUNCH((qkv256p_kernel<bf16_t>), dim3(persistent_grid(total)), dim3(512), g256::LDS_BYTES + ROPE_LDS_BYTES, st, *p, ntb, ntg2, total);
-      } else {
-        const int ok = allow_big_lds(qkv256p_kernel<f16_t>, g256::LDS_BYTES + ROPE_LDS_BYTES);
-        if (ok != OVG_OK) return ok;
-        OVG_LAUNCH((qkv256p_kernel<f16_t>), dim3(persistent_grid(total)), dim3(512), g256::LDS_BYTES + ROPE_LDS_BYTES, st, *p, ntb, ntg2, total);
-      }
-      OVG_CHECK_LAUNCH();
-      return OVG_OK;
-    }
     if (p->dtype == OVG_BF16) {
       const int ok = allow_big_lds(qkv256_kernel<bf16_t>, g256::LDS_BYTES + ROPE_LDS_BYTES);
       if (ok != OVG_OK) return ok;

@@ -150,135 +150,4 @@ OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict_
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Persistent form (r03): one workgroup per CU walks a strided list of tiles, and the k-stages of consecutive tiles form ONE
-// stream through the 4-slot ring: the first three stages of tile i + 1 are issued in the last three L sections of tile i, so
-// when the epilogue of tile i is done its successor's operands are already in LDS.
-// Why: at K = 1024 a 256 x 256 tile is 32 stages x 0.78 us = 25 us of main loop under a FIXED 11.6 us of workgroup dispatch,
-// kernel-argument / address set-up, pipeline fill (three stages requested, first one ~1.5 us away), drain and epilogue
-// (two-point fit over the square STORE problems, profiles/r02_gemm_persistent_ab.txt: 111.5 us for 128 stages, 211.4 us for 256):
-// a third of every QKV / fc1 / proj tile. The r02 persistent experiment let the two wave groups run their epilogues one barrier
-// apart -- each then waited for the other's (the ping-pong barriers pair across groups) and the epilogues serialised (-10..-23 %).
-// Here the structure of ONE tile is unchanged (prologue barrier P, ping-pong loop, group 0's closing barrier = both groups leave
-// the loop together and run their epilogues side by side); only the dispatch, the set-up and the fill disappear.
-//   ring slots: nk % 4 == 0 (K = 1024 / 4096), so every tile starts at slot 0 and "stage t + 3 reuses the slot of stage t - 1"
-//   holds across the seam exactly as inside a tile (RAW / WAR argument of the header above, with t counted along the stream).
-// ---------------------------------------------------------------------------------------------------------------------
-// This lane's DMA source rows of one tile (k = 0): four plain pointers (a struct selected at run time would live in scratch).
-// This lane's DMA source rows of one tile (k = 0): four plain pointers (a struct selected at run time would live in scratch).
-struct TileSrc { const unsigned char* w0; const unsigned char* w1; const unsigned char* x0; const unsigned char* x1; };
-
-template <typename T>
-OVG_DEV TileSrc tile_sources(const T* __restrict__ X, int64_t ldx, const T* __restrict__ W, int64_t ldw, int M, int N, int m0, int n0) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int row0 = wave * 32 + (lane >> 2), row1 = row0 + 16;
-  int wr0 = n0 + row0, wr1 = n0 + row1, xr0 = m0 + row0, xr1 = m0 + row1;
-  wr0 = wr0 < N ? wr0 : N - 1; wr1 = wr1 < N ? wr1 : N - 1;
-  xr0 = xr0 < M ? xr0 : M - 1; xr1 = xr1 < M ? xr1 : M - 1;
-  const int ch0 = ((lane & 3) ^ swz64(row0)) * 16, ch1 = ((lane & 3) ^ swz64(row1)) * 16;
-  TileSrc s;
-  s.w0 = reinterpret_cast<const unsigned char*>(W + (int64_t)wr0 * ldw) + ch0;
-  s.w1 = reinterpret_cast<const unsigned char*>(W + (int64_t)wr1 * ldw) + ch1;
-  s.x0 = reinterpret_cast<const unsigned char*>(X + (int64_t)xr0 * ldx) + ch0;
-  s.x1 = reinterpret_cast<const unsigned char*>(X + (int64_t)xr1 * ldx) + ch1;
-  return s;
-}
-
-// One tile of the stream. `first`: nothing of this tile has been requested yet (the workgroup's first tile); `has_next`: the last
-// three L sections request stages 0..2 of `nxt`. Leaves acc as mainloop() does.
-template <typename T, bool SWAP>
-OVG_DEV void mainloop_stream(const TileSrc cur, const TileSrc nxt, const bool first, const bool has_next, const int K,
-                             unsigned char* lds, f32x4 (&acc)[4][8]) {
-  static_assert(sizeof(T) == 2, "16-bit operands");
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave & 3, wm = wave >> 2;
-  const int g = lane >> 4, lr = lane & 15;
-  const int nk = (K * 2) / ROWB;                                  // % 4 == 0 (checked by the host)
-  auto stage = [&](int t3) {                                      // stream stage t3 = t + 3 of THIS tile's numbering
-    const bool nx = t3 >= nk;                                     // wave-uniform
-    if (nx && !has_next) return;
-    const int64_t koff = (int64_t)(nx ? t3 - nk : t3) * ROWB;
-    const unsigned char* w0 = nx ? nxt.w0 : cur.w0;
-    const unsigned char* w1 = nx ? nxt.w1 : cur.w1;
-    const unsigned char* x0 = nx ? nxt.x0 : cur.x0;
-    const unsigned char* x1 = nx ? nxt.x1 : cur.x1;
-    unsigned char* wb = lds + (t3 & (SLOTS - 1)) * STAGE_B + wave * 32 * ROWB;
-    unsigned char* xb = wb + W_TILE;
-    __builtin_amdgcn_global_load_lds((gptr_t)(w0 + koff), (lptr_t)(wb), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(x0 + koff), (lptr_t)(xb), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(w1 + koff), (lptr_t)(wb + 16 * ROWB), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(x1 + koff), (lptr_t)(xb + 16 * ROWB), 16, 0, 0);
-  };
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int frag_off = lr * ROWB + (g ^ swz64(lr)) * 16;
-  const int w_off = wn * 64 * ROWB + frag_off, x_off = W_TILE + wm * 128 * ROWB + frag_off;
-  u32x4 a[4], b[8];
-  auto read_frags = [&](int kt) {
-    const unsigned char* base = lds + (kt & (SLOTS - 1)) * STAGE_B;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const u32x4*>(base + w_off + t * 16 * ROWB);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) b[t] = *reinterpret_cast<const u32x4*>(base + x_off + t * 16 * ROWB);
-  };
-  auto mfmas = [&]() {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int mt = 0; mt < 8; ++mt) {
-        if constexpr (SWAP) TT<T>::mma(acc[nt][mt], b[mt], a[nt]);
-        else TT<T>::mma(acc[nt][mt], a[nt], b[mt]);
-      }
-    __builtin_amdgcn_s_setprio(0);
-  };
-  auto in_flight_after = [&](int t) {                             // stages requested beyond stream stage t when the wave has requested up to t + 2
-    if (has_next) return 2;
-    const int last = (t + 2) < (nk - 1) ? (t + 2) : (nk - 1);
-    return last - t;
-  };
-
-  if (first)
-    for (int s = 0; s < 3; ++s) stage(s);
-  wait_tiles_in_flight(in_flight_after(0));
-  __builtin_amdgcn_s_barrier();                      // P: stage 0 of this tile visible to every wave
-
-  if (wm == 0) {
-    for (int t = 0; t < nk; ++t) {
-      read_frags(t);                                 // L(t)
-      stage(t + 3);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();                  // b(2t)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas();                                       // M(t)
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < nk) wait_tiles_in_flight(in_flight_after(t + 1));   // w(t+1)
-      __builtin_amdgcn_s_barrier();                  // b(2t+1)
-    }
-    __builtin_amdgcn_s_barrier();                    // pairs with group 1's last barrier: both groups reach their epilogues together
-  } else {
-    __builtin_amdgcn_s_barrier();                    // b0: one barrier behind group 0
-    for (int t = 0; t < nk; ++t) {
-      read_frags(t);                                 // L(t)
-      stage(t + 3);
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < nk) wait_tiles_in_flight(in_flight_after(t + 1));   // w(t+1)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                  // b(2t+1)
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas();                                       // M(t)
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();                  // b(2t+2)
-    }
-  }
-}
-
-
-
 }  // namespace g256

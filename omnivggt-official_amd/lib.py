@@ -15,7 +15,8 @@ EPI_STORE, EPI_GELU, EPI_RES, EPI_PATCH = 0, 1, 2, 3
 OVG_MAX_SEG = 8
 KV_TILE = 64
 ABI_VERSION = 7
-TILE_AUTO, TILE_128, TILE_256, TILE_256X, TILE_256P = 0, 1, 2, 3, 4
+TILE_AUTO, TILE_128, TILE_256 = 0, 1, 2
+TILE_R02_EPILOGUE, TILE_128X, TILE_256X = 16, 17, 18      # A/B flag (r02 epilogue forms) OR-ed onto a tile selector
 
 ERRORS = {0: "OVG_OK", -1: "OVG_E_ARG", -2: "OVG_E_DTYPE", -3: "OVG_E_LAUNCH", -4: "OVG_E_UNSUPPORTED"}
 

@@ -79,14 +79,6 @@ def test_gemm256_r02_gelu_form_behind_the_knob():
     _assert_clean()
 
 
-def test_gemm256_persistent_stream_every_epilogue_ragged_m():
-    """OVG_TILE_256P: one workgroup per CU walking a tile list, consecutive tiles' k-stages one stream through the LDS ring --
-    every epilogue / all three QKV parts / ragged M / in-place residual / K = 640 (PATCH), from 4 tiles (each workgroup one tile,
-    no successor) to 5504 tiles (21.5 per workgroup)."""
-    st.test_gemm256(False, tile=L.TILE_256P, auto_is=False)
-    _assert_clean()
-
-
 def test_global_attention_at_bench_key_counts():
     """N = 10 992 / 21 984 in full, N = 87 936 on sampled rows: the launches the bench times."""
     st.test_attn_big(False)
