@@ -823,7 +823,9 @@ int launch_linear256(const ovg_linear_params& p, hipStream_t st, bool xp) {
 // 1.8-1.9 GHz and attention at 2.1-2.2 GHz, and the GEMMs' own in-situ gain shrinks with cold L2s and one workgroup per
 // CU). Re-measured with the LDS-DMA attention kernels (profiles/r02_gemm_tile_in_situ.txt, second block): 8 views 190.1 (128 x 128) vs
 // 189.0 frames/s, 16 views + aux 155.5 vs 156.8 (256 x 256) -- so the 256 x 256 kernels are used from M >= 20 000 rows (16 views) on,
-// where they are worth +1 % (16 views) ... +2 % (64 views) on the forward.
+// where they are worth +1 % (16 views) ... +2 % (64 views) on the forward. Re-checked in r03 with the staged-store epilogues
+// (profiles/r03_gemm_mlp256_insitu.txt): fc1 / fc2 alone on 256 x 256 below the threshold -- isolated +8 / +17 % at M = 10 992 -- still
+// LOSES in situ (4 / 8 / 12 views: -6.5 / -4 / -2.5 %; the global attention behind them 0.445 -> 0.482 ms): the threshold stays.
 // Returns 1 = use 256^2, 0 = use 128^2, -1 = the caller forced a tile this shape / dtype cannot run.
 int choose_256(int tile_arg, bool sixteen_bit, int64_t M, int64_t N, int64_t K, bool light_epilogue_or_long_k) {
   const int tile = tile_arg & ~OVG_TILE_R02_EPILOGUE;      // the A/B flag does not take part in the tile choice
