@@ -334,8 +334,8 @@ int ovg_copy_rows(const ovg_copy_rows_params*, void* stream);
 
 /* ================================================================== *
  * DPT dense-prediction head (reference heads/dpt_head.py:185-304,
- * heads/head_act.py:61-125).  16-bit modes only (OVG_BF16 / OVG_F16, f32 accumulate); the f32
- * parity mode keeps the PyTorch head.  Activations are NHWC: [n_img, H, W, C] with a pixel
+ * heads/head_act.py:61-125).  OVG_BF16 / OVG_F16 (f32 accumulate) and, since ABI 7, OVG_F32 (the parity mode: exact-f32 MFMA,
+ * activations / weights / outputs all f32, Cin % 32 == 0 instead of % 64).  Activations are NHWC: [n_img, H, W, C] with a pixel
  * stride (ld, in elements) >= C.
  * ================================================================== */
 
@@ -366,7 +366,7 @@ int ovg_head_layernorm(const ovg_head_layernorm_params*, void* stream);
  *         [s*s*Cout, Cin] ordered (dy, dx, co), bias is [Cout]; GEMM row (i, oy, ox), column (dy, dx, co)
  *         is stored at y[i, oy*s+dy, ox*s+dx, co].  pos / add are not supported together with upshuffle.
  *   out_f32 != 0: y is f32.
- * Constraints: Cin % 64 == 0; w holds w_rows rows (a multiple of 128, zero rows beyond the Cout_gemm real ones,
+ * Constraints: Cin % 64 == 0 (OVG_F32: % 32); w holds w_rows rows (a multiple of 128, zero rows beyond the Cout_gemm real ones,
  * Cout_gemm = Cout, or s*s*Cout with upshuffle: then it must itself be the multiple of 128); Cout % 4 == 0. */
 typedef struct {
   const void* x; int64_t ldx;

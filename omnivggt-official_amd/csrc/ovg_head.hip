@@ -2,7 +2,8 @@
 // heads/dpt_head.py as NHWC implicit GEMMs on the MFMA, with the element-wise glue the reference runs
 // as separate ATen ops (bias, in-place ReLU of the ResidualConvUnits, residual / skip sums, UV position
 // embedding, ConvTranspose2d pixel scatter) folded into the GEMM epilogue; plus LayerNorm(2048),
-// align_corners bilinear resize and the 1x1 + activation output stage. 16-bit modes only.
+// align_corners bilinear resize and the 1x1 + activation output stage. All three dtypes: the 16-bit modes and (r03) the f32 parity mode
+// on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32 through TT<float>::mma, 32-channel k chunks instead of 64).
 #include "ovg_common.h"
 
 namespace {
@@ -57,8 +58,8 @@ OVG_DEV void conv_mainloop(const ovg_conv_params& p, const int M, const int OH, 
   const int wn = wave >> 1, wm = wave & 1;
   const int g = lane >> 4, lr = lane & 15;
   const int ks = p.ksize, pad = ks >> 1, taps = ks * ks;
-  const int64_t ktot_b = (int64_t)taps * p.Cin * 2;          // bytes per weight row
-  const int64_t pix_b = p.ldx * 2;                           // bytes per input pixel
+  const int64_t ktot_b = (int64_t)taps * p.Cin * (int64_t)sizeof(T);   // bytes per weight row
+  const int64_t pix_b = p.ldx * (int64_t)sizeof(T);                    // bytes per input pixel
 
   const unsigned char* xc[4];
   const unsigned char* wg[4];
@@ -85,7 +86,7 @@ OVG_DEV void conv_mainloop(const ovg_conv_params& p, const int M, const int OH, 
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int cpt = p.Cin / 64;                                 // k-tiles per tap
+  const int cpt = p.Cin / (BKB / (int)sizeof(T));             // k-tiles (128 B of channels) per tap
   const int nk = taps * cpt;
   u32x4 rx[4], rw[4];
   int tap = 0, cc = 0;                                        // (tap, chunk) of the k-tile being fetched
@@ -308,6 +309,7 @@ extern "C" int ovg_head_layernorm(const ovg_head_layernorm_params* p, void* stre
   switch (p->dtype) {
     case OVG_BF16: OVG_LAUNCH((head_layernorm_kernel<bf16_t>), grid, block, 0, st, *p); break;
     case OVG_F16: OVG_LAUNCH((head_layernorm_kernel<f16_t>), grid, block, 0, st, *p); break;
+    case OVG_F32: OVG_LAUNCH((head_layernorm_kernel<float>), grid, block, 0, st, *p); break;
     default: return OVG_E_DTYPE;
   }
   OVG_CHECK_LAUNCH();
@@ -318,12 +320,14 @@ extern "C" int ovg_conv(const ovg_conv_params* p, void* stream) {
   if (!p || !p->x || !p->w || !p->y) return OVG_E_ARG;
   if (p->n_img <= 0 || p->H <= 0 || p->W <= 0 || p->Cin <= 0 || p->Cout <= 0) return OVG_E_ARG;
   if ((p->ksize != 1 && p->ksize != 3) || (p->stride != 1 && p->stride != 2)) return OVG_E_ARG;
-  if (p->Cin % 64 || p->Cout % 4 || p->w_rows <= 0 || p->w_rows % 128) return OVG_E_ARG;
+  if (p->dtype != OVG_BF16 && p->dtype != OVG_F16 && p->dtype != OVG_F32) return OVG_E_DTYPE;
+  const int kchunk = p->dtype == OVG_F32 ? 32 : 64;           // channels per 128-byte k chunk
+  if (p->Cin % kchunk || p->Cout % 4 || p->w_rows <= 0 || p->w_rows % 128) return OVG_E_ARG;
   const int s = p->upshuffle > 1 ? p->upshuffle : 1;
   if (s > 1 && (p->ksize != 1 || p->stride != 1 || p->pos_x || p->add1 || p->add2 || p->w_rows != s * s * p->Cout)) return OVG_E_ARG;
   if (s == 1 && p->w_rows < p->Cout) return OVG_E_ARG;
   if ((p->pos_x == nullptr) != (p->pos_y == nullptr) || (p->pos_x && (p->Cout % 8))) return OVG_E_ARG;
-  if (p->ldx < p->Cin || (p->ldx % 8) || p->ldy < p->Cout || (p->ldy % 4)) return OVG_E_ARG;
+  if (p->ldx < p->Cin || (p->ldx % (p->dtype == OVG_F32 ? 4 : 8)) || p->ldy < p->Cout || (p->ldy % 4)) return OVG_E_ARG;
   if (!al16(p->x) || !al16(p->w) || !al16(p->y) || (p->bias && !al16(p->bias))) return OVG_E_ARG;
   if ((p->add1 && (!al16(p->add1) || (p->ld1 % 4))) || (p->add2 && (!al16(p->add2) || (p->ld2 % 4)))) return OVG_E_ARG;
   const int pad = p->ksize / 2;
@@ -340,7 +344,7 @@ extern "C" int ovg_conv(const ovg_conv_params* p, void* stream) {
     if (p->out_f32) OVG_LAUNCH((conv_kernel<f16_t, true>), grid, block, 0, st, *p, OH, OW, M, nt);
     else OVG_LAUNCH((conv_kernel<f16_t, false>), grid, block, 0, st, *p, OH, OW, M, nt);
   } else {
-    return OVG_E_DTYPE;
+    OVG_LAUNCH((conv_kernel<float, true>), grid, block, 0, st, *p, OH, OW, M, nt);   // f32 activations: y is f32 whatever out_f32 says
   }
   OVG_CHECK_LAUNCH();
   return OVG_OK;
@@ -358,6 +362,7 @@ extern "C" int ovg_upsample(const ovg_upsample_params* p, void* stream) {
   switch (p->dtype) {
     case OVG_BF16: OVG_LAUNCH((upsample_kernel<bf16_t>), grid, block, 0, st, *p, sy, sx, total); break;
     case OVG_F16: OVG_LAUNCH((upsample_kernel<f16_t>), grid, block, 0, st, *p, sy, sx, total); break;
+    case OVG_F32: OVG_LAUNCH((upsample_kernel<float>), grid, block, 0, st, *p, sy, sx, total); break;
     default: return OVG_E_DTYPE;
   }
   OVG_CHECK_LAUNCH();

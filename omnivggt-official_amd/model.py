@@ -10,7 +10,9 @@
 fp32 end to end -- inference.py has no autocast, omnivggt.py:45 disables it around the heads: exact-f32 MFMA,
 matches the reference CPU path to <= 1e-4 relative), torch.bfloat16 or torch.float16 (throughput modes, an explicit
 opt-in: ~14x faster, tokens within the bf16-autocast twin's own error, profiles/r02_lowprec_parity.txt).  Heads: in the f32 parity
-mode all three run as f32 PyTorch modules, like the reference (autocast disabled around them, omnivggt.py:45). In the 16-bit
+mode the two DPT heads run on the same HIP kernels in f32 (exact-f32 MFMA implicit-GEMM convolutions, r03; `hip_heads_f32=False`
+puts them back on PyTorch / MIOpen) and the camera head is the f32 PyTorch module, like the reference (autocast disabled around
+the heads, omnivggt.py:45). In the 16-bit
 modes the two DPT heads run on the HIP kernels (heads_hip.py: 16-bit NHWC implicit-GEMM convolutions) and the camera head on
 ovg_camera_head (16-bit weight streams; residual stream, statistics, softmax and the pose accumulation in f32);
 `hip_heads=False` forces the PyTorch heads everywhere, `hip_camera_head=False` only the camera head (pose_enc then carries
@@ -32,10 +34,11 @@ except Exception:  # pragma: no cover - optional
 
 class OmniVGGT(nn.Module, _HubMixin):
     def __init__(self, img_size=518, patch_size=14, embed_dim=1024, depth=24, dino_depth=24,
-                 compute_dtype=torch.float32, dpt_layers=(4, 11, 17, 23), hip_heads=True, hip_camera_head=True):
+                 compute_dtype=torch.float32, dpt_layers=(4, 11, 17, 23), hip_heads=True, hip_camera_head=True, hip_heads_f32=True):
         super().__init__()
         self.hip_heads = hip_heads
         self.hip_camera_head = hip_camera_head
+        self.hip_heads_f32 = hip_heads_f32          # f32 parity mode: DPT heads on the HIP f32 kernels (False: PyTorch / MIOpen modules)
         self.aggregator = ZeroAggregator(img_size=img_size, patch_size=patch_size, embed_dim=embed_dim, depth=depth,
                                          dino_depth=dino_depth, pose_hidden_dim=9, compute_dtype=compute_dtype)
         layers = tuple(min(l, depth - 1) for l in dpt_layers)
@@ -58,8 +61,8 @@ class OmniVGGT(nn.Module, _HubMixin):
 
     def _dpt(self, which, head, tokens, imgs32, patch_start_idx):
         dt = self.aggregator.compute_dtype
-        if self.hip_heads and dt in (torch.bfloat16, torch.float16) and imgs32.is_cuda:
-            return self._hip_dpt[which](tokens, imgs32, patch_start_idx, dtype=dt)
+        if self.hip_heads and imgs32.is_cuda and (dt in (torch.bfloat16, torch.float16) or self.hip_heads_f32):
+            return self._hip_dpt[which](tokens, imgs32, patch_start_idx, dtype=dt)     # f32: exact-f32 MFMA convolutions (r03)
         return head(tokens, images=imgs32, patch_start_idx=patch_start_idx)
 
     def set_compute_dtype(self, dtype):

@@ -279,14 +279,15 @@ def test_attn(quick):
 
 def test_heads(quick):
     """DPT-head entries (ovg_head_layernorm / ovg_conv / ovg_upsample / ovg_dpt_out) against their torch
-    emulation (tests/head_ops_emul.py) on the same 16-bit inputs, then the whole HipDPTHead against the
-    f32 PyTorch head on CPU."""
+    emulation (tests/head_ops_emul.py) on the same inputs in all three dtypes (f32 = the parity mode's exact-f32 MFMA
+    convolutions, r03), then the whole HipDPTHead against the f32 PyTorch head on CPU (f32 gate 1e-4: the same
+    arithmetic up to summation order and the out_conv-before-upsample reordering)."""
     import head_ops_emul as emul
     import importlib
     heads = importlib.import_module("omnivggt_official_amd.heads")
     heads_hip = importlib.import_module("omnivggt_official_amd.heads_hip")
     g = torch.Generator().manual_seed(9)
-    for name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+    for name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16), ("f32", torch.float32)):
         tol = TOL[name]
         # LayerNorm(2048) with the special-token skip
         x = rnd(2 * 1374, 2048, g=g) * 2.0 + 0.3
@@ -356,10 +357,11 @@ def test_heads(quick):
             rv, rc = head(toks, images=images, patch_start_idx=5)
             hip = heads_hip.HipDPTHead(head)
             toks_d = [t.to(DEV) for t in toks]
-            for name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+            for name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16), ("f32", torch.float32)):
                 val, conf = hip(toks_d, images.to(DEV), 5, dtype=dt)
-                report("dpt_head_%s_%s_val" % (act, name), val, rv, 4e-2 if name == "bf16" else 6e-3)
-                report("dpt_head_%s_%s_conf" % (act, name), conf, rc, 4e-2 if name == "bf16" else 6e-3)
+                gate = {"bf16": 4e-2, "f16": 6e-3, "f32": 1e-4}[name]
+                report("dpt_head_%s_%s_val" % (act, name), val, rv, gate)
+                report("dpt_head_%s_%s_conf" % (act, name), conf, rc, gate)
             if quick:
                 break
 
