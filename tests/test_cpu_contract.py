@@ -262,3 +262,24 @@ def test_vt_column_order_helpers():
         ops.set_vt(vt, v.to(dt))
         nat = ops.get_vt(vt)
         assert torch.equal(nat[:, :, :70], v.to(dt)) and float(nat[:, :, 70:].abs().max()) == 0.0
+
+
+def test_bench_watchdog_dumps_stacks_prints_the_partial_line_and_exits(tmp_path):
+    """bench.py's per-rank watchdog (round-2 review: a hung collective must leave a diagnosable record): a rank that makes no
+    progress for `timeout` seconds writes a rank- and stage-tagged message plus every thread's stack to stderr, rank 0 prints the
+    JSON line with what was measured so far and a `watchdog` record, and the process exits with code 3."""
+    import json
+    import sys
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "partial = {'metric': 'm', 'value': 12.5, 'n_gpus': 2}\n"
+            "wd = bench.Watchdog(0, 2, 1.5, partial)\n"
+            "wd.stage('second form: allgather')\n"
+            "time.sleep(30)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] == 12.5 and line["watchdog"]["stage"] == "second form: allgather" and line["watchdog"]["rank"] == 0
+    assert "[rank 0/2" in r.stderr and "WATCHDOG: no progress" in r.stderr and "Thread" in r.stderr
+    # a non-zero rank dumps its stacks but prints no JSON line (rank 0 owns stdout)
+    r1 = subprocess.run([sys.executable, "-c", code.replace("Watchdog(0, 2", "Watchdog(1, 2")], capture_output=True, text=True, timeout=120)
+    assert r1.returncode == 3 and r1.stdout.strip() == "" and "[rank 1/2]" in r1.stderr

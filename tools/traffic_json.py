@@ -59,7 +59,8 @@ def main():
             b = m.get("FETCH_SIZE", 0.0) * 1024 * 2 + m.get("WRITE_SIZE", 0.0) * 1024
             total += b
             hit += m.get("TCC_HIT_sum", 0.0); miss += m.get("TCC_MISS_sum", 0.0)
-            parts.append({"kernel": key[0].split("attn")[-1][:60], "grid": key[1], "bytes": round(b)})
+            i = key[0].find("attn")
+            parts.append({"kernel": key[0][i:i + 64], "grid": key[1], "bytes": round(b)})
         n = S * 1374
         rec["global_attn_S%d_bytes_per_launch" % S] = round(total)
         rec["global_attn_S%d_algorithmic_bytes" % S] = 4 * n * 1024 * 2
