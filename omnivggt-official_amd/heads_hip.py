@@ -7,7 +7,8 @@ skip / UV-position-embedding / ConvTranspose pixel scatter folded into its epilo
 stay in the wrapped `DPTHead` (same state-dict keys); they are re-packed (NHWC tap order, 16-bit) on
 first use per device / dtype.
 
-Used by `OmniVGGT` when the compute dtype is bf16 / f16; the f32 parity mode keeps the PyTorch head.
+Used by `OmniVGGT` in all three compute dtypes (f32 parity mode: exact-f32 MFMA convolutions, r03; `OmniVGGT(hip_heads_f32=False)`
+keeps the PyTorch head there).
 Differences from the reference's arithmetic (all exact in real arithmetic, measured in the tests):
   * the 1x1 `out_conv` of each fusion block runs BEFORE the bilinear upsampling instead of after
     (both are linear and the interpolation weights sum to one): 4x fewer FLOPs;
