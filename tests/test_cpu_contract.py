@@ -283,3 +283,17 @@ def test_bench_watchdog_dumps_stacks_prints_the_partial_line_and_exits(tmp_path)
     # a non-zero rank dumps its stacks but prints no JSON line (rank 0 owns stdout)
     r1 = subprocess.run([sys.executable, "-c", code.replace("Watchdog(0, 2", "Watchdog(1, 2")], capture_output=True, text=True, timeout=120)
     assert r1.returncode == 3 and r1.stdout.strip() == "" and "[rank 1/2]" in r1.stderr
+
+
+def test_committed_traffic_record_matches_the_attention_sources():
+    """profiles/traffic.json (what bench.py prints as roofline.traffic) is tied to the sha256 of the attention sources it was measured
+    on; the committed record must describe the committed kernels -- editing ovg_attn.hip / ovg_attn16.h / ovg_common.h without
+    re-taking the PMC passes (tools/validate_r03.sh -> tools/traffic_json.py) fails here instead of printing a stale figure."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert rec["attention_source_digest"] == bench.attention_source_digest()
+    for S in (8, 64):
+        assert rec["global_attn_S%d_bytes_per_launch" % S] >= rec["global_attn_S%d_algorithmic_bytes" % S] == 4 * S * 1374 * 1024 * 2
