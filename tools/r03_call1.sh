@@ -1,4 +1,5 @@
 #!/bin/bash
+# RECORD of an intermediate pass: run on tree a744f67 (tile 3 = the first r03 epilogue forms, since replaced); kept as the provenance of profiles/r03_gemm_epilogue_forms_ab.txt, r03_attention_tail256_ab.txt, r03_multirank_one_gpu_gloo.txt.
 # Round-3 GPU pass 1: the -m gpu suite (new: headline / stress configs vs the oracle, 8 emulated ranks, camera tables, f16 outliers),
 # A/B of the r03 GEMM epilogue forms and of the 256-row attention tail split, the default bench line, the N = 2/4/8 control flow on one GPU.
 set -u

@@ -1,4 +1,5 @@
 #!/bin/bash
+# RECORD of an intermediate pass: run on tree dc56e19 (tile 4 = the persistent-stream kernels, since removed); provenance of profiles/r03_gemm_persistent_ab.txt, r03_attention_tail256_sweep.txt.
 # Round-3 GPU pass 2: the persistent-stream 256 x 256 GEMMs (OVG_TILE_256P) -- parity, isolated A/B against the one-tile-per-workgroup
 # kernels at 8 / 16 / 32 / 64 views, in-situ A/B on the whole forward; finer sweep of the 256-row attention tail split.
 set -u

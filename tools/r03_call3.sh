@@ -1,4 +1,5 @@
 #!/bin/bash
+# RECORD of an intermediate pass: run on tree 21591a0; provenance of profiles/r03_gemm_staged_stores_ab.txt (tile flag 16 = OVG_TILE_R02_EPILOGUE still exists).
 # Round-3 GPU pass 3: whole-line stores staged through the idle LDS (both GEMM tile sizes, QK head rows): parity, isolated A/B against the
 # r02 epilogue forms (tile flag 16), in-situ A/B on the whole forward at 64 / 16 / 8 views.
 set -u

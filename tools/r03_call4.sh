@@ -1,4 +1,5 @@
 #!/bin/bash
+# RECORD of an intermediate pass: run on a throw-away build of 21591a0 + a block-level flag 32 (fc1 / fc2 forced onto 256 x 256), removed in 8714e52; provenance of profiles/r03_gemm_mlp256_insitu.txt.
 # in-situ A/B: MLP GEMMs (fc1 / fc2) on the 256 x 256 kernels below the 20 000-row threshold (gemm_tile flag 32)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}

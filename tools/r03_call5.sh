@@ -1,4 +1,5 @@
 #!/bin/bash
+# Run on tree 07381af; provenance of profiles/r03_f32_e2e_hip_vs_pytorch_heads.txt.
 # Round-3 GPU pass 5: the DPT heads of the f32 parity mode on the HIP f32 kernels -- kernel / whole-head parity, the f32 end-to-end tests
 # against the oracle and the reference goldens, and the f32 end-to-end forward timed with HIP and with PyTorch (MIOpen) heads.
 set -u
