@@ -297,3 +297,36 @@ def test_committed_traffic_record_matches_the_attention_sources():
     assert rec["attention_source_digest"] == bench.attention_source_digest()
     for S in (8, 64):
         assert rec["global_attn_S%d_bytes_per_launch" % S] >= rec["global_attn_S%d_algorithmic_bytes" % S] == 4 * S * 1374 * 1024 * 2
+
+
+def test_traffic_json_tool_sums_the_dispatches_of_one_attention_and_stamps_the_digest(tmp_path):
+    """tools/traffic_json.py: bytes per global attention = sum over the (kernel, grid) dispatches of the launch plan of
+    FETCH_SIZE[KiB] * 1024 * 2 (gfx950 wide-read correction, MI355X_MICROARCH.md) + WRITE_SIZE[KiB] * 1024, from the two separate
+    rocprofv3 --pmc passes; kernels that are not the tuned attention (the baseline reference call of the bench tool) are ignored."""
+    import csv
+    import json
+    import sys
+    hdr = ["Kernel_Name", "Grid_Size", "Counter_Name", "Counter_Value"]
+    main, tail = "void attn16_kernel<__bf16, 4, 8, 0, 2, false, 5>(ovg_attn_params)", "void attn16_kernel<__bf16, 2, 4, 0, 2, false, 3>(ovg_attn_params)"
+    rows_fetch = [[main, 1310720, "FETCH_SIZE", 1000.0], [main, 1310720, "FETCH_SIZE", 1200.0], [main, 1310720, "TCC_HIT_sum", 96.0],
+                  [tail, 192512, "FETCH_SIZE", 300.0], [tail, 192512, "TCC_HIT_sum", 4.0], ["void attn_kernel<float, 1>(x)", 704512, "FETCH_SIZE", 9e9]]
+    rows_write = [[main, 1310720, "WRITE_SIZE", 500.0], [main, 1310720, "TCC_MISS_sum", 3.0], [tail, 192512, "WRITE_SIZE", 100.0], [tail, 192512, "TCC_MISS_sum", 1.0]]
+    for name, rows in (("p3", rows_fetch), ("p4", rows_write)):
+        d = tmp_path / name / "runc"
+        d.mkdir(parents=True)
+        with open(d / "1_counter_collection.csv", "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(hdr)
+            w.writerows(rows)
+    out = tmp_path / "traffic.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "traffic_json.py"), "--views", "64", str(tmp_path / "p3"), str(tmp_path / "p4"),
+                        "--out", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.load(open(out))
+    want = (1100.0 * 2048 + 500.0 * 1024) + (300.0 * 2048 + 100.0 * 1024)
+    assert rec["global_attn_S64_bytes_per_launch"] == round(want)
+    assert rec["global_attn_S64_algorithmic_bytes"] == 4 * 64 * 1374 * 1024 * 2
+    assert abs(rec["global_attn_S64_l2_hit_rate"] - 100.0 / 104.0) < 1e-3 and len(rec["global_attn_S64_dispatches"]) == 2
+    sys.path.insert(0, ROOT)
+    import bench
+    assert rec["attention_source_digest"] == bench.attention_source_digest()
