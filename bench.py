@@ -65,6 +65,8 @@ def kernel_name(dtype_name, n_q, n_k):
     from omnivggt_official_amd import ops
     plan = ops.attn_plan(16, n_q, [n_k], DT[dtype_name])
     name = KERNEL_NAME[dtype_name] % (min(plan["q_tile"] // 64, 8), plan["q_tile"])
+    if plan["tail_q_tile"]:
+        name += "; rows %d.. of every head in a second launch of %d-row tiles" % (plan["main_rows"], plan["tail_q_tile"])
     return name + (", split-KV x%d" % plan["splits"] if plan["splits"] > 1 else "")
 PARITY_LAYERS = (0, 4, 11, 17, 23)
 

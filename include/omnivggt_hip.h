@@ -187,7 +187,12 @@ int ovg_flash_attn(const ovg_attn_params*, void* stream);
 
 /* Host-only query: how ovg_flash_attn would run this call with kv_splits == 0 (needs nq, BH, dtype, variant, the
  * segments' nk; pointers are ignored) and how much split workspace the caller should provide for it. */
-typedef struct { int splits; int q_tile; int64_t part_bytes; int64_t lse_bytes; } ovg_attn_plan_out;
+typedef struct {
+  int splits; int q_tile; int64_t part_bytes; int64_t lse_bytes;
+  /* tail split of long launches (ABI 7): rows [0, main_rows) of every batch entry run as q_tile-row tiles in a first launch, the rest as
+   * tail_q_tile-row tiles in a second one; main_rows == nq and tail_q_tile == 0 when the call is one launch */
+  int64_t main_rows; int tail_q_tile;
+} ovg_attn_plan_out;
 int ovg_attn_plan(const ovg_attn_params*, ovg_attn_plan_out* out);
 
 /* Combine two attention results over disjoint key sets (same queries):

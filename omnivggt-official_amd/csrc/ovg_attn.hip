@@ -276,7 +276,8 @@ int launch_attn(const ovg_attn_params& p, hipStream_t st) {
 // 512-row tiles take those (1 workgroup of 8 waves per CU: every staged K / V^T tile feeds twice the rows; 16 views +5.9 %,
 // 64 views +3 %, 8 views -17 % -- profiles/r02_attention_dma_ab.txt), with the rows beyond the last full round in a second
 // launch of 128-row tiles (dispatch16).
-struct Plan16 { int variant; int bq; int splits; int per_split; int total_tiles; };
+struct Plan16 { int variant; int bq; int splits; int per_split; int total_tiles;
+                int64_t main_rows; int tail_bq; };   // tail split: rows [0, main_rows) of every entry in the first launch (bq-row tiles), the rest in a second one of tail_bq-row tiles (0 = none)
 
 int cu_count_attn() {
   static const int n = [] {
@@ -344,6 +345,26 @@ Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
   if (splits > pl.total_tiles) splits = pl.total_tiles;
   pl.per_split = (pl.total_tiles + splits - 1) / splits;
   pl.splits = (pl.total_tiles + pl.per_split - 1) / pl.per_split;       // every pass non-empty
+  // ---- tail split (unsplit launches of the two default bf16 kernels; variants 71 / 72 force it for the A/B tool) ----
+  // 512-row kernel (one workgroup per CU): a launch of R = units / CUs rounds pays a whole round -- or more: nothing to overlap with -- for its
+  // fractional last one (tools/probes/attn_tail_probe.py, 64 views: 22.18 ms for 10.0 rounds, 24.91 ms for 10.75: +4.6 % per row). The full
+  // rounds keep the 512-row tiles; the remaining rows of every head go to a second launch of 128-row tiles (three workgroups per CU) that
+  // spreads them over the whole chip. Measured (profiles/r02_attention_dma_ab.txt): 16 / 24 / 32 / 48 / 64 views +1.5 / +11.5 / +7.6 / +4.1 / +1.5 %
+  // over the unsplit 512-row launch and best-or-within-1.3 % of the best of {256-row, 512-row} x {split, unsplit} at every size.
+  // 256-row kernel (two workgroups per CU) in the 1 .. 2.5-round regime, 8 to 14 views on one GPU (profiles/r03_attention_tail256_ab.txt,
+  // r03_attention_tail256_sweep.txt): 9 / 10 views (1.53 / 1.69 rounds) +6.3 / +4.5 %; 8 views (1.34 rounds) -4 % -- a third-full second round of
+  // lone workgroups (one per CU, the whole CU's LDS bandwidth and issue slots to itself) already runs fast; 13 / 14 views (2.19 / 2.38 rounds)
+  // +1.8 / -3 %. So: exactly one full round and at least half a round of tail.
+  pl.main_rows = p.nq; pl.tail_bq = 0;
+  if (pl.splits == 1 && (v == 57 || v == 50) && (p.variant == 0 || p.variant == (v == 57 ? 71 : 72)) && (v == 57 || p.nq >= 4096)) {
+    const int tslots = v == 57 ? cus : 2 * cus;
+    const int64_t full = units / tslots;
+    const double frac = (double)units / tslots - (double)full;
+    const int64_t rows_a = full * tslots / p.BH * pl.bq;
+    const bool want = v == 57 ? (full >= 2 && frac > 0.05)
+                              : (p.variant == 72 ? (full >= 1 && frac > 0.05) : (full == 1 && frac > 0.5));
+    if (want && frac < 0.85 && rows_a > 0 && rows_a < p.nq) { pl.main_rows = rows_a; pl.tail_bq = 128; }
+  }
   return pl;
 }
 
@@ -388,40 +409,10 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
     const int64_t rows = (int64_t)pl.splits * p.BH * p.nq_pad;
     if (p.ws_part_bytes < rows * OVG_D * 2 || p.ws_lse_bytes < rows * 4) return OVG_E_ARG;
   }
-  // Tail split of the 512-row kernel (automatic plan; variant 71 forces it for the A/B tool): a launch of R = units / 256 rounds pays
-  // a whole round -- or more: one workgroup per CU, nothing to overlap with -- for its fractional last one (tools/probes/attn_tail_probe.py,
-  // 64 views: 22.18 ms for 10.0 rounds, 24.91 ms for 10.75: +4.6 % per row). The full rounds keep the 512-row tiles; the remaining rows of
-  // every head go to a second launch of 128-row tiles (three workgroups per CU) that spreads them over the whole chip. Measured
-  // (profiles/r02_attention_dma_ab.txt): 16 / 24 / 32 / 48 / 64 views +1.5 / +11.5 / +7.6 / +4.1 / +1.5 % over the unsplit 512-row launch and
-  // best-or-within-1.3 % of the best of {256-row, 512-row} x {split, unsplit} at every size.
-  if ((p.variant == 0 || p.variant == 71) && pl.splits == 1 && pl.variant == 57) {
-    const int slots = cu_count_attn();
-    const int64_t units = p.BH * ((p.nq + pl.bq - 1) / pl.bq);
-    const int64_t full = units / slots;
-    const double frac = (double)units / slots - (double)full;
-    const int64_t rows_a = full * slots / p.BH * pl.bq;
-    if (full >= 2 && frac > 0.05 && frac < 0.85 && rows_a > 0 && rows_a < p.nq) {
-      const int rc = launch_attn16<T, 4, 8, 0, 2, false, 5>(p, pl, st, 0, rows_a);
-      return rc != OVG_OK ? rc : launch_attn16<T, 2, 4, 0, 2, false, 3>(p, pl, st, rows_a, p.nq);
-    }
-  }
-  // The same split for the 256-row kernel (two workgroups per CU) in the 1 .. 2.5-round regime -- 8 to 14 views on one GPU: 688 workgroups
-  // on 512 slots at 8 views leave the second "round" a third full, one workgroup per CU on 176 CUs. The first full round(s) keep the 256-row
-  // tiles, the remaining rows of every head go to 128-row tiles (three per CU) over the whole chip.
-  if ((p.variant == 0 || p.variant == 72) && pl.splits == 1 && pl.variant == 50 && p.nq >= 4096) {
-    const int slots = 2 * cu_count_attn();
-    const int64_t units = p.BH * ((p.nq + pl.bq - 1) / pl.bq);
-    const int64_t full = units / slots;
-    const double frac = (double)units / slots - (double)full;
-    const int64_t rows_a = full * slots / p.BH * pl.bq;
-    // measured (profiles/r03_attention_tail256_ab.txt, r03_attention_tail256_sweep.txt): 9 / 10 views (1.53 / 1.69 rounds) +6.3 / +4.5 %; 8 views
-    // (1.34 rounds) -4 % -- a third-full second round of lone workgroups (one per CU, the whole CU's LDS bandwidth and issue slots to itself)
-    // already runs fast; 13 / 14 views (2.19 / 2.38 rounds) +1.8 / -3 %. So: exactly one full round and at least half a round of tail.
-    const bool want = p.variant == 72 ? (full >= 1 && frac > 0.05) : (full == 1 && frac > 0.5);
-    if (want && frac < 0.85 && rows_a > 0 && rows_a < p.nq) {
-      const int rc = launch_attn16<T, 4, 4, 0, 2, false, 3>(p, pl, st, 0, rows_a);
-      return rc != OVG_OK ? rc : launch_attn16<T, 2, 4, 0, 2, false, 3>(p, pl, st, rows_a, p.nq);
-    }
+  if (pl.tail_bq) {                                 // tail split (plan16): full rounds of big tiles, then the remaining rows as 128-row tiles
+    const int rc = pl.variant == 57 ? launch_attn16<T, 4, 8, 0, 2, false, 5>(p, pl, st, 0, pl.main_rows)
+                                    : launch_attn16<T, 4, 4, 0, 2, false, 3>(p, pl, st, 0, pl.main_rows);
+    return rc != OVG_OK ? rc : launch_attn16<T, 2, 4, 0, 2, false, 3>(p, pl, st, pl.main_rows, p.nq);
   }
   switch (pl.variant) {
     case 1: return launch_attn<T, 1>(p, st);
@@ -479,12 +470,12 @@ extern "C" int ovg_attn_plan(const ovg_attn_params* p, ovg_attn_plan_out* out) {
   if (!p || !out || p->nq <= 0 || p->BH <= 0 || p->nseg < 1 || p->nseg > OVG_MAX_SEG || p->kv_splits < 0 || p->kv_splits > OVG_MAX_SEG) return OVG_E_ARG;
   for (int i = 0; i < p->nseg; ++i)
     if (p->seg[i].nk <= 0) return OVG_E_ARG;
-  out->splits = 1; out->q_tile = 64; out->part_bytes = 0; out->lse_bytes = 0;
+  out->splits = 1; out->q_tile = 64; out->part_bytes = 0; out->lse_bytes = 0; out->main_rows = p->nq; out->tail_q_tile = 0;
   if (p->dtype != OVG_BF16 && p->dtype != OVG_F16) return p->dtype == OVG_F32 ? OVG_OK : OVG_E_DTYPE;
   const Plan16 pl = plan16(*p, p->dtype == OVG_BF16, true);
   if (pl.variant == 1 || pl.variant == 2) return OVG_OK;
   const int64_t nq_pad = p->nq_pad >= p->nq ? p->nq_pad : ((p->nq + BC - 1) / BC) * BC;
-  out->splits = pl.splits; out->q_tile = pl.bq;
+  out->splits = pl.splits; out->q_tile = pl.bq; out->main_rows = pl.main_rows; out->tail_q_tile = pl.tail_bq;
   if (pl.splits > 1) {
     out->part_bytes = (int64_t)pl.splits * p->BH * nq_pad * OVG_D * 2;
     out->lse_bytes = (int64_t)pl.splits * p->BH * nq_pad * 4;

@@ -55,7 +55,7 @@ class AttnParams(C.Structure):
 
 
 class AttnPlanOut(C.Structure):
-    _fields_ = [("splits", i32), ("q_tile", i32), ("part_bytes", i64), ("lse_bytes", i64)]
+    _fields_ = [("splits", i32), ("q_tile", i32), ("part_bytes", i64), ("lse_bytes", i64), ("main_rows", i64), ("tail_q_tile", i32)]
 
 
 class AttnMergeParams(C.Structure):

@@ -120,7 +120,7 @@ def qkv(x, w, bias, seq, dtype, q, k, vt, qk_norm=None, rope=None, tokens_per_vi
 
 
 def attn_plan(BH, nq, nks, dtype, variant=0, kv_splits=0, nq_pad=None):
-    """How ovg_flash_attn would run this shape (host-only query): dict(splits, q_tile, part_bytes, lse_bytes).
+    """How ovg_flash_attn would run this shape (host-only query): dict(splits, q_tile, part_bytes, lse_bytes, main_rows, tail_q_tile).
     nq_pad: row count of the q buffer the call will use (default: nq padded to 64); the partial buffers are sized with it."""
     p = L.AttnParams()
     p.nq, p.nq_pad, p.BH, p.nseg = nq, (pad_to(nq, KV_TILE) if nq_pad is None else nq_pad), BH, len(nks)
@@ -129,7 +129,8 @@ def attn_plan(BH, nq, nks, dtype, variant=0, kv_splits=0, nq_pad=None):
     p.dtype, p.variant, p.kv_splits = L.dtype_code(dtype), variant, kv_splits
     out = L.AttnPlanOut()
     L.check(L.load().ovg_attn_plan(L.C.byref(p), L.C.byref(out)), "ovg_attn_plan")
-    return {"splits": out.splits, "q_tile": out.q_tile, "part_bytes": out.part_bytes, "lse_bytes": out.lse_bytes}
+    return {"splits": out.splits, "q_tile": out.q_tile, "part_bytes": out.part_bytes, "lse_bytes": out.lse_bytes,
+            "main_rows": out.main_rows, "tail_q_tile": out.tail_q_tile}
 
 
 def alloc_split_ws(plan, device):

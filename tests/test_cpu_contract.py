@@ -330,3 +330,31 @@ def test_traffic_json_tool_sums_the_dispatches_of_one_attention_and_stamps_the_d
     sys.path.insert(0, ROOT)
     import bench
     assert rec["attention_source_digest"] == bench.attention_source_digest()
+
+
+def test_attention_launch_plan_of_the_baseline_shapes():
+    """ovg_attn_plan is a host-only query (256 CUs assumed where no device is visible): the launch plan of every BASELINE shape is pinned
+    here so that a plan regression shows up on CPU -- q tile, the tail split (rows of the first launch + tile of the second) and the
+    split-KV factor of the per-rank launches of the view-sharded run."""
+    from omnivggt_official_amd import ops
+    P = 1374
+    bf, f16 = torch.bfloat16, torch.float16
+    plan = lambda BH, nq, nks, dt, **kw: ops.attn_plan(BH, nq, nks, dt, **kw)
+    # single GPU, global attention (16 heads, nq = nk = S * 1374)
+    p8 = plan(16, 8 * P, [8 * P], bf)
+    assert (p8["q_tile"], p8["tail_q_tile"], p8["main_rows"]) == (256, 0, 8 * P)            # 1.34 rounds: the tail split loses there (-4 %)
+    for S in (9, 10):
+        p = plan(16, S * P, [S * P], bf)
+        assert (p["q_tile"], p["tail_q_tile"], p["main_rows"]) == (256, 128, 8192), (S, p)     # one full round of 512 slots, then 128-row tiles
+    for S, rows in ((16, 16384), (64, 81920)):                                                 # 2 / 10 full rounds of 512-row tiles on 256 CUs
+        p = plan(16, S * P, [S * P], bf)
+        assert (p["q_tile"], p["tail_q_tile"], p["main_rows"]) == (512, 128, rows), (S, p)
+    p128 = plan(16, 128 * P, [128 * P], f16)
+    assert (p128["q_tile"], p128["tail_q_tile"], p128["splits"]) == (256, 0, 1)               # f16: the lazy-rescale kernel, 256-row tiles
+    # frame-local attention (S * 16 entries of 1374 rows): the tile that pads the sequence least once the launch is long enough
+    assert plan(64 * 16, P, [P], bf)["q_tile"] == 128 and plan(8 * 16, P, [P], bf)["q_tile"] == 256
+    # per-rank launches of the 8-GPU run, head-parallel form: 16 (source rank, head) entries x 8 views of queries x 8 segments of keys
+    pr = plan(16, 8 * P, [8 * P] * 8, bf)
+    assert (pr["splits"], pr["q_tile"], pr["tail_q_tile"]) == (4, 256, 0) and pr["part_bytes"] == 4 * 16 * ops.pad_to(8 * P, 64) * 64 * 2
+    # a forced factor is honoured and sized; the baseline kernel (variant 1) never splits
+    assert plan(16, 8 * P, [8 * P], bf, kv_splits=3)["splits"] == 3 and plan(16, 8 * P, [8 * P], bf, variant=1)["splits"] == 1
