@@ -40,7 +40,8 @@ extern "C" {
  *    ovg_block_workspace_bytes, ovg_pack_weights, split-KV attention (kv_splits / ws_part / ws_lse, ovg_attn_plan)
  * 5-6: camera head entry; 16-bit V^T rows in the PV fragment order (LDS-DMA staged attention)
  * 7: split-KV workspace SIZES travel with the pointers (ws_part_bytes / ws_lse_bytes: an undersized workspace is OVG_E_ARG
- *    instead of an out-of-bounds write), ovg_camera_tables (camera-modality injection tables built on the device) */
+ *    instead of an out-of-bounds write), ovg_camera_tables (camera-modality injection tables built on the device), OVG_F32 in the DPT-head
+ *    entries, ovg_attn_plan_out.main_rows / tail_q_tile (the tail split of long attention launches is part of the queryable plan) */
 #define OVG_ABI_VERSION 7
 
 enum { OVG_BF16 = 0, OVG_F16 = 1, OVG_F32 = 2 };
