@@ -201,7 +201,7 @@ def test_low_precision_modes_vs_twin(full_model, name):
     reference golden AND against the same-precision twin -- the reference itself under torch.autocast('cpu', bfloat16)
     on the same weights / inputs (oracle/gen_golden_bf16twin.py). Gate: on every aggregator layer and on pose_enc the
     HIP error vs the f32 reference is <= 2x the twin's own error (max-rel AND rms-rel); the dense predictions, which pass
-    through the 16-bit DPT heads (a "next" row), <= 3x. The measured table is appended to gpurun_out/r02_lowprec_parity.txt."""
+    through the 16-bit DPT heads (a "next" row), <= 3x. The measured table is appended to gpurun_out/lowprec_parity.txt."""
     S, dgi, cgi, hw = common.case(name)
     gold, twin = common.load_golden(name), common.load_golden(name + "_bf16twin")
     keys = ["tok_L%d" % l for l in common.TOK_LAYERS] + ["pose_enc", "depth", "depth_conf", "world_points", "world_points_conf"]
@@ -231,7 +231,7 @@ def test_low_precision_modes_vs_twin(full_model, name):
     text = "\n".join(lines)
     print(text)
     os.makedirs(os.path.join(common.ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(common.ROOT, "gpurun_out", "r02_lowprec_parity.txt"), "a") as fh:
+    with open(os.path.join(common.ROOT, "gpurun_out", "lowprec_parity.txt"), "a") as fh:
         fh.write(text + "\n\n")
     for k in keys:
         factor = 2.0 if (k.startswith("tok_") or k == "pose_enc") else 3.0
