@@ -405,7 +405,7 @@ def main():
                 ms = (time.perf_counter() - t1) / 3 * 1e3
                 result["e2e"] = {"views": Se, "frames_per_s": round(Se / ms * 1e3, 3), "ms_per_forward": round(ms, 3),
                                  "dpt_heads": "pytorch-f32" if (args.torch_heads or (args.dtype == "f32" and not model.hip_heads_f32)) else "hip-" + args.dtype,
-                                 "camera_head": "pytorch-f32" if (args.torch_heads or args.dtype == "f32") else "hip-" + args.dtype}
+                                 "camera_head": "pytorch-f32" if (args.torch_heads or (args.dtype == "f32" and not model.hip_heads_f32)) else "hip-" + args.dtype}
             except Exception as e:  # never let the heads hide the hot-path number
                 result["e2e_error"] = repr(e)[:200]
         if not args.no_cpu_baseline:

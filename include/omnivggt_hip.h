@@ -439,10 +439,11 @@ int ovg_heads_to_tokens(const ovg_heads_to_tokens_params*, void* stream);
  * encodings of every refinement round (absT_quaR_FoV: translation and quaternion linear, field of view ReLU,
  * heads/head_act.py:12-35). One call issues every launch of every round; nothing is read back in between.
  *   GEMM weights (mod_w [6144,2048], blk[i].qkv_w [6144,2048], proj_w [2048,2048], fc1_w [8192,2048],
- *   fc2_w [2048,8192], pb1_w [1024,2048]) in `dtype` (OVG_BF16 / OVG_F16; nn.Linear layout, K contiguous, 16-byte
- *   aligned); every vector, the 9-wide embed_pose [2048,9] and pose_branch.fc2 [9,1024] matrices and all activations
- *   that carry state (residual stream, statistics, softmax, pose) f32. OVG_F32 -> OVG_E_UNSUPPORTED (the f32 parity
- *   mode keeps the PyTorch module). dim must be 2048, heads 16 (head dim 128), trunk_depth <= OVG_CAMERA_MAX_TRUNK,
+ *   fc2_w [2048,8192], pb1_w [1024,2048]) in `dtype` (OVG_BF16 / OVG_F16 / OVG_F32; nn.Linear layout, K contiguous,
+ *   16-byte aligned); every vector, the 9-wide embed_pose [2048,9] and pose_branch.fc2 [9,1024] matrices and all
+ *   activations that carry state (residual stream, statistics, softmax, pose) f32. With OVG_F32 (the parity mode) the
+ *   GEMM operands and the activation buffers between kernels are f32 too and the products run on the exact-f32 MFMA:
+ *   no rounding point below f32 anywhere. dim must be 2048, heads 16 (head dim 128), trunk_depth <= OVG_CAMERA_MAX_TRUNK,
  *   S <= 4096. ws: caller-owned scratch of >= ovg_camera_head_workspace_bytes(S, dtype) bytes (returns -1 on bad args).
  * ------------------------------------------------------------------ */
 #define OVG_CAMERA_MAX_TRUNK 4

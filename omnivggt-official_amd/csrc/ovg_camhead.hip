@@ -5,14 +5,15 @@
 // (heads/head_act.py:12-35: translation / quaternion linear, field of view ReLU)] -- on S camera tokens.
 //
 // Shape of the problem: M = S rows (8 ... 128) against 216 M weight parameters per round. Every GEMM is a weight
-// STREAM (2 bytes per parameter per round, 1.7 GB over the four rounds in the 16-bit modes), i.e. HBM bound; the MFMA
-// only has to keep up with the loads. So:
+// STREAM (2 bytes per parameter per round, 1.7 GB over the four rounds in the 16-bit modes; twice that in the f32 parity
+// mode, whose GEMM operands and activation buffers are f32 and whose products run on the exact-f32 MFMA), i.e. HBM bound;
+// the MFMA only has to keep up with the loads. So:
 //  * ch_gemm_partial: one wave = 16 weight rows x a K range, the weight fragments go global -> registers -> MFMA A operand
 //    (each element is used once per 64 tokens: no LDS staging), the S token rows are the B operand (L2 resident);
 //    split-K over enough workgroups to fill the chip (>= 512 where K allows), deterministic: every split writes its own f32 partial;
 //  * the partial sums are folded by the CONSUMER: the row kernels (bias + LayerScale + residual + the next LayerNorm in one
 //    pass over the 2048-wide row), the adaLN modulation, the pose update; only QKV and fc1 have a stand-alone finish
-//    (bias / bias + exact GELU -> 16 bit);
+//    (bias / bias + exact GELU -> compute dtype);
 //  * attention over S keys with head dim 128 is ~1 MFLOP per head: one 128-thread workgroup per (head, query), f32.
 // One C call issues the ~41 launches of a round back to back (the host never looks at intermediate results).
 // Always f32: residual stream, LayerNorm statistics, softmax, biases, LayerScale, the 9-wide pose tensors.
@@ -25,11 +26,12 @@ constexpr int CH = 2048, CH_HEADS = 16, CH_HD = 128, CH_HID = 8192, CH_MOD = 614
 constexpr int CH_MAX_S = 4096;            // attention scores of one query live in LDS
 constexpr int CH_PART_COLS = 32768;       // ksplit * N of any GEMM here (partial buffer = S x this many floats)
 
-template <typename T> OVG_DEV void unpack8(const u32x4& raw, float (&f)[8]) {
-  T v[8];
+// one 16-byte chunk = TT<T>::kPerChunk elements (8 in the 16-bit modes, 4 in f32)
+template <typename T> OVG_DEV void unpack_chunk(const u32x4& raw, float (&f)[TT<T>::kPerChunk]) {
+  T v[TT<T>::kPerChunk];
   __builtin_memcpy(v, &raw, 16);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) f[i] = TT<T>::to_f32(v[i]);
+  for (int i = 0; i < TT<T>::kPerChunk; ++i) f[i] = TT<T>::to_f32(v[i]);
 }
 
 // sum over the 256 threads of a workgroup (red: 4 floats of LDS, reusable after the call returns on all threads)
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void ch_residual_kernel(const float* part, int
   row_layernorm(r, n_w, n_b, n_eps, red).store_t<T>(xn + (int64_t)m * CH);
 }
 
-// ---- stand-alone finish: out = sum of partials + bias (EPI 0) / exact-erf GELU of it (EPI 1), 16-bit -----------------------
+// ---- stand-alone finish: out = sum of partials + bias (EPI 0) / exact-erf GELU of it (EPI 1), in the compute dtype ---------
 template <typename T, int EPI>
 __global__ __launch_bounds__(256) void ch_finish_kernel(const float* part, int ksplit, int S, int N, const float* bias, T* out) {
   const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one thread = 4 columns of one row
@@ -169,8 +171,10 @@ __global__ __launch_bounds__(256) void ch_finish_kernel(const float* part, int k
 
 // ---- split-K weight-streaming GEMM: part[ks][m][n] = sum_{k in chunk ks} x[m][k] * w[n][k] ---------------------------------
 // grid (N / 64, ksplit, ceil(S / 64)), 4 waves: wave v owns weight rows n0 + 16 v .. + 15 (the MFMA A operand, straight from
-// global memory: lane (r = lane & 15, g = lane >> 4) supplies w[n0 + r][k0 + 8 g .. + 7]); the <= 64 token rows of the z slice
-// are the B operand. Result lane (c, g) holds out[m0 + 16 mb + c][n0 + 4 g .. + 3] -> one 16-byte store per 16-token block.
+// global memory: lane (r = lane & 15, g = lane >> 4) supplies w[n0 + r][k0 + E g .. + E - 1], E = elements per 16 bytes: 8 in the
+// 16-bit modes (one 16x16x32 MFMA per fragment), 4 in f32 (four exact-f32 16x16x4 MFMAs, TT<float>::mma)); the <= 64 token rows
+// of the z slice are the B operand. Result lane (c, g) holds out[m0 + 16 mb + c][n0 + 4 g .. + 3] -> one 16-byte store per
+// 16-token block.
 template <typename T>
 __global__ __launch_bounds__(256) void ch_gemm_partial_kernel(const T* x, int64_t ldx, const T* w, int64_t ldw, float* part, int S, int N, int kchunk) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -179,27 +183,28 @@ __global__ __launch_bounds__(256) void ch_gemm_partial_kernel(const T* x, int64_
   const int k_begin = blockIdx.y * kchunk;
   const int m0 = blockIdx.z * 64;
   const int nmb = (S - m0 + 15) / 16 < 4 ? (S - m0 + 15) / 16 : 4;
-  const T* wp = w + (int64_t)(n0 + r) * ldw + k_begin + 8 * g;
+  constexpr int E = TT<T>::kPerChunk;               // a fragment (one 16-byte load per lane) covers 4 E consecutive k
+  const T* wp = w + (int64_t)(n0 + r) * ldw + k_begin + E * g;
   const T* xp[4];
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
     int m = m0 + 16 * mb + r;
     m = m < S ? m : S - 1;
-    xp[mb] = x + (int64_t)m * ldx + k_begin + 8 * g;
+    xp[mb] = x + (int64_t)m * ldx + k_begin + E * g;
   }
   f32x4 acc[4];
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < kchunk; k += 256) {          // kchunk % 256 == 0 (host); 8 weight fragments (8 KB per wave) in flight
+  for (int k = 0; k < kchunk; k += 32 * E) {       // kchunk % 256 == 0 (host); 8 weight fragments (8 KB per wave) in flight
     u32x4 wf[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) wf[u] = *reinterpret_cast<const u32x4*>(wp + k + 32 * u);
+    for (int u = 0; u < 8; ++u) wf[u] = *reinterpret_cast<const u32x4*>(wp + k + 4 * E * u);
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
       if (mb < nmb) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const u32x4 xf = *reinterpret_cast<const u32x4*>(xp[mb] + k + 32 * u);
+          const u32x4 xf = *reinterpret_cast<const u32x4*>(xp[mb] + k + 4 * E * u);
           TT<T>::mma(acc[mb], wf[u], xf);
         }
       }
@@ -227,12 +232,13 @@ __global__ __launch_bounds__(128) void ch_attn_kernel(const T* qkv, T* out, int 
   for (int j = t; j < S; j += 128) {
     const T* kr = qkv + (int64_t)j * 3 * CH + CH + h * CH_HD;
     float s = 0.f;
+    constexpr int E = TT<T>::kPerChunk;
 #pragma unroll
-    for (int c = 0; c < CH_HD / 8; ++c) {
-      float kf[8];
-      unpack8<T>(*reinterpret_cast<const u32x4*>(kr + 8 * c), kf);
+    for (int c = 0; c < CH_HD / E; ++c) {
+      float kf[E];
+      unpack_chunk<T>(*reinterpret_cast<const u32x4*>(kr + E * c), kf);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) s += qs[8 * c + i] * kf[i];
+      for (int i = 0; i < E; ++i) s += qs[E * c + i] * kf[i];
     }
     ps[j] = s;
     lmax = fmaxf(lmax, s);
@@ -388,8 +394,8 @@ int run(const ovg_camera_head_params& p, hipStream_t st) {
 }  // namespace
 
 extern "C" int64_t ovg_camera_head_workspace_bytes(int32_t S, int32_t dtype) {
-  if (S <= 0 || S > CH_MAX_S || (dtype != OVG_BF16 && dtype != OVG_F16)) return -1;
-  return carve(nullptr, S, 2).total;
+  if (S <= 0 || S > CH_MAX_S || (dtype != OVG_BF16 && dtype != OVG_F16 && dtype != OVG_F32)) return -1;
+  return carve(nullptr, S, dtype == OVG_F32 ? 4 : 2).total;
 }
 
 extern "C" int ovg_camera_head(const ovg_camera_head_params* p, void* stream) {
@@ -397,8 +403,8 @@ extern "C" int ovg_camera_head(const ovg_camera_head_params* p, void* stream) {
   if (p->S <= 0 || p->iters <= 0 || p->ld_tokens < CH || (p->ld_tokens & 3)) return OVG_E_ARG;
   if (p->S > CH_MAX_S || p->trunk_depth < 1 || p->trunk_depth > OVG_CAMERA_MAX_TRUNK) return OVG_E_UNSUPPORTED;
   if (p->dim != CH || p->heads != CH_HEADS) return OVG_E_UNSUPPORTED;
-  if (p->dtype != OVG_BF16 && p->dtype != OVG_F16) return p->dtype == OVG_F32 ? OVG_E_UNSUPPORTED : OVG_E_DTYPE;
-  if (p->ws_bytes < carve(nullptr, p->S, 2).total) return OVG_E_ARG;
+  if (p->dtype != OVG_BF16 && p->dtype != OVG_F16 && p->dtype != OVG_F32) return OVG_E_DTYPE;
+  if (p->ws_bytes < carve(nullptr, p->S, p->dtype == OVG_F32 ? 4 : 2).total) return OVG_E_ARG;
   const void* req[] = {p->token_norm_w, p->token_norm_b, p->trunk_norm_w, p->trunk_norm_b, p->empty_pose, p->embed_w, p->embed_b,
                        p->mod_w, p->mod_b, p->pb1_w, p->pb1_b, p->pb2_w, p->pb2_b};
   for (const void* q : req)
@@ -413,5 +419,5 @@ extern "C" int ovg_camera_head(const ovg_camera_head_params* p, void* stream) {
   }
   if ((reinterpret_cast<uintptr_t>(p->tokens) | reinterpret_cast<uintptr_t>(p->ws) | reinterpret_cast<uintptr_t>(p->mod_w) | reinterpret_cast<uintptr_t>(p->pb1_w)) & 15) return OVG_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  return p->dtype == OVG_BF16 ? run<bf16_t>(*p, st) : run<f16_t>(*p, st);
+  return p->dtype == OVG_BF16 ? run<bf16_t>(*p, st) : p->dtype == OVG_F16 ? run<f16_t>(*p, st) : run<float>(*p, st);
 }

@@ -162,8 +162,8 @@ class HipDPTHead:
 
 class HipCameraHead:
     """Camera head on the `ovg_camera_head` entry (csrc/ovg_camhead.hip): the iterative pose regressor of
-    heads/camera_head.py:84-154 with its six kinds of GEMM as split-K weight streams on the MFMA, in the 16-bit
-    compute dtype; the parameters stay in the wrapped `heads.CameraHead` (same state-dict keys) and are re-packed
+    heads/camera_head.py:84-154 with its six kinds of GEMM as split-K weight streams on the MFMA, in the compute
+    dtype (bf16 / f16, or f32 on the exact-f32 MFMA in the parity mode); the parameters stay in the wrapped `heads.CameraHead` (same state-dict keys) and are re-packed
     on first use per device / dtype. One C call per batch element issues all ~165 launches of the four rounds."""
 
     def __init__(self, head):

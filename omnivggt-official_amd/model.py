@@ -10,9 +10,9 @@
 fp32 end to end -- inference.py has no autocast, omnivggt.py:45 disables it around the heads: exact-f32 MFMA,
 matches the reference CPU path to <= 1e-4 relative), torch.bfloat16 or torch.float16 (throughput modes, an explicit
 opt-in: ~14x faster, tokens within the bf16-autocast twin's own error, profiles/r02_lowprec_parity.txt).  Heads: in the f32 parity
-mode the two DPT heads run on the same HIP kernels in f32 (exact-f32 MFMA implicit-GEMM convolutions, r03; `hip_heads_f32=False`
-puts them back on PyTorch / MIOpen) and the camera head is the f32 PyTorch module, like the reference (autocast disabled around
-the heads, omnivggt.py:45). In the 16-bit
+mode the two DPT heads and the camera head run on the same HIP kernels in f32 (exact-f32 MFMA implicit-GEMM convolutions and
+weight streams, no rounding point below f32, like the reference which disables autocast around the heads, omnivggt.py:45;
+`hip_heads_f32=False` puts all three back on the PyTorch / MIOpen modules). In the 16-bit
 modes the two DPT heads run on the HIP kernels (heads_hip.py: 16-bit NHWC implicit-GEMM convolutions) and the camera head on
 ovg_camera_head (16-bit weight streams; residual stream, statistics, softmax and the pose accumulation in f32);
 `hip_heads=False` forces the PyTorch heads everywhere, `hip_camera_head=False` only the camera head (pose_enc then carries
@@ -38,7 +38,7 @@ class OmniVGGT(nn.Module, _HubMixin):
         super().__init__()
         self.hip_heads = hip_heads
         self.hip_camera_head = hip_camera_head
-        self.hip_heads_f32 = hip_heads_f32          # f32 parity mode: DPT heads on the HIP f32 kernels (False: PyTorch / MIOpen modules)
+        self.hip_heads_f32 = hip_heads_f32          # f32 parity mode: all three heads on the HIP f32 kernels (False: PyTorch / MIOpen modules)
         self.aggregator = ZeroAggregator(img_size=img_size, patch_size=patch_size, embed_dim=embed_dim, depth=depth,
                                          dino_depth=dino_depth, pose_hidden_dim=9, compute_dtype=compute_dtype)
         layers = tuple(min(l, depth - 1) for l in dpt_layers)
@@ -55,7 +55,8 @@ class OmniVGGT(nn.Module, _HubMixin):
     def _camera(self, cam_tokens):
         dt = self.aggregator.compute_dtype
         toks = cam_tokens[-1]
-        if self.hip_heads and self.hip_camera_head and dt in (torch.bfloat16, torch.float16) and toks.is_cuda and toks.shape[1] <= 4096:
+        lowp = dt in (torch.bfloat16, torch.float16)
+        if self.hip_heads and self.hip_camera_head and (lowp or self.hip_heads_f32) and toks.is_cuda and toks.shape[1] <= 4096:
             return self._hip_cam(cam_tokens, dtype=dt)
         return self.camera_head(cam_tokens)
 

@@ -96,7 +96,9 @@ def test_argument_validation_without_gpu():
     for S in (1, 8, 128):
         want = 2 * r(S * 2048 * 4) + r(S * 9 * 4) + r(S * 32768 * 4) + 3 * r(S * 2048 * 2) + r(S * 6144 * 2) + r(S * 8192 * 2)
         assert lib.ovg_camera_head_workspace_bytes(S, L.OVG_BF16) == want
-    assert lib.ovg_camera_head_workspace_bytes(8, L.OVG_F32) == -1 and lib.ovg_camera_head_workspace_bytes(0, L.OVG_BF16) == -1
+        want32 = 2 * r(S * 2048 * 4) + r(S * 9 * 4) + r(S * 32768 * 4) + 3 * r(S * 2048 * 4) + r(S * 6144 * 4) + r(S * 8192 * 4)
+        assert lib.ovg_camera_head_workspace_bytes(S, L.OVG_F32) == want32       # f32 parity mode: f32 activation buffers
+    assert lib.ovg_camera_head_workspace_bytes(8, 99) == -1 and lib.ovg_camera_head_workspace_bytes(0, L.OVG_BF16) == -1
 
 
 def test_block_workspace_query_matches_the_python_allocation():
