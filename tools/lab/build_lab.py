@@ -20,6 +20,7 @@ import importlib
 
 B = importlib.import_module("omnivggt_official_amd.build")
 import gen_pipe_body as G  # noqa: E402
+import gen_pipe32_body as G32  # noqa: E402
 
 OUT = os.path.join(HERE, "_build")
 
@@ -133,6 +134,28 @@ def skew_experiment(n):
         since_barrier = 0;''' % n)]
 
 
+A32_INC_OLD = '''// variant (benchmark / test knob; numbers kept from the A/B logs under profiles/):'''
+A32_BQ_OLD = '''  pl.bq = (v == 33 || v == 51 || v == 57 || v == 58 || v == 59) ? 512 : '''
+A32_SLOTS_OLD = '''  const int slots = (v == 33 || v == 51 || v == 57 || v == 58 || v == 59) ? cus : 2 * cus;'''
+A32_CASE_OLD = '''    case 59: return launch_attn16<T, 4, 8, 0, 2, false, 9>(p, pl, st);'''
+
+
+def attn32_experiment(schedule):
+    """The 32x32x16-MFMA speculative pass as a NEW file in the copy (ovg_attn32_lab.h) + its dispatch: variants 80 / 81 = order-pinned
+    body with 512- / 256-row q tiles, 82 / 83 = the same kernels with the plain HIP body on every tile."""
+    body = G32.emit(G32.generate(schedule))
+    header = open(os.path.join(HERE, "ovg_attn32_lab.h.in")).read().replace("@NAME@", schedule).replace("@BODY@", body)
+    return [("+ovg_attn32_lab.h", None, header),
+            ("ovg_attn.hip", A32_INC_OLD, '#include "ovg_attn32_lab.h"\n' + A32_INC_OLD),
+            ("ovg_attn.hip", A32_BQ_OLD, "  pl.bq = (v == 33 || v == 51 || v == 57 || v == 58 || v == 59 || v == 80 || v == 82) ? 512 : "),
+            ("ovg_attn.hip", A32_SLOTS_OLD, "  const int slots = (v == 33 || v == 51 || v == 57 || v == 58 || v == 59 || v == 80 || v == 82) ? cus : 2 * cus;"),
+            ("ovg_attn.hip", A32_CASE_OLD, A32_CASE_OLD + '''
+    case 80: return launch_attn32<T, 8, 5, true>(p, pl, st);
+    case 81: return launch_attn32<T, 4, 3, true>(p, pl, st);
+    case 82: return launch_attn32<T, 8, 5, false>(p, pl, st);
+    case 83: return launch_attn32<T, 4, 3, false>(p, pl, st);''')]
+
+
 EXPERIMENTS = {
     "control": [],                                   # the product sources, rebuilt through the same path
     "prio_young": prio_experiment("young"),          # MI355X_MICROARCH.md, two waves per SIMD, item 4: s_setprio 1 for waves 4-7
@@ -143,6 +166,10 @@ EXPERIMENTS = {
     "pipe_v1_prio": pipe_experiment("v1") + prio_experiment("young"),
     "pipe_v4": pipe_experiment("v4"),
     "pipe_v5": pipe_experiment("v5"),
+    "attn32_w1": attn32_experiment("w1"),
+    "attn32_w2": attn32_experiment("w2"),
+    "attn32_x1": attn32_experiment("x1"),
+    "attn32_x2": attn32_experiment("x2"),
     "skew1": skew_experiment(1),
     "skew2": skew_experiment(2),
     "pipe_v4_skew1": pipe_experiment("v4") + skew_experiment(1),
@@ -170,6 +197,9 @@ def build(name):
     shutil.copy(os.path.join(ROOT, "include", "omnivggt_hip.h"), os.path.join(d, "include"))
     touched = set()
     for f, old, new in subs:
+        if f.startswith("+"):                           # a new file of the copy
+            open(os.path.join(csrc, f[1:]), "w").write(new)
+            continue
         p = os.path.join(csrc, f)
         s = open(p).read()
         assert s.count(old) == 1, "experiment %s: anchor not found exactly once in %s: %r" % (name, f, old[:60])

@@ -14,7 +14,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <int PER, int NE, int NC, int NM>
+template <int PER, int NE, int NC, int NM, int NACC = 8>
 __global__ __launch_bounds__(512) void mix(float* out, long long* cyc, int iters) {
   f32x4 acc[8];
   for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(512) void mix(float* out, long long* cyc, int iters
 #pragma unroll
     for (int g = 0; g < G; ++g) {
 #pragma unroll
-      for (int k = 0; k < PER; ++k) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, %0" : "+v"(acc[(g * PER + k) & 7]) : "v"(a));
+      for (int k = 0; k < PER; ++k) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, %0" : "+v"(acc[(g * PER + k) & (NACC - 1)]) : "v"(a));
 #pragma unroll
       for (int j = 0; j < NE; ++j) asm volatile("v_exp_f32 %0, %0" : "+v"(e[(g * NE + j) & 7]));
 #pragma unroll
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(512) void mix(float* out, long long* cyc, int iters
 
 // The same with v_mfma_f32_32x32x16_bf16 (twice the FLOP per issued instruction, 32 matrix-pipe cycles): 4 independent accumulators of 16 registers
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-template <int PER, int NE, int NC, int NM>
+template <int PER, int NE, int NC, int NM, int NACC = 4>
 __global__ __launch_bounds__(512) void mix32(float* out, long long* cyc, int iters) {
   f32x16 acc[4];
   for (int i = 0; i < 4; ++i)
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(512) void mix32(float* out, long long* cyc, int ite
 #pragma unroll
     for (int g = 0; g < G; ++g) {
 #pragma unroll
-      for (int k = 0; k < PER; ++k) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %1, %0" : "+v"(acc[(g * PER + k) & 3]) : "v"(a));
+      for (int k = 0; k < PER; ++k) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %1, %0" : "+v"(acc[(g * PER + k) & (NACC - 1)]) : "v"(a));
 #pragma unroll
       for (int j = 0; j < NE; ++j) asm volatile("v_exp_f32 %0, %0" : "+v"(e[(g * NE + j) & 7]));
 #pragma unroll
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(512) void mix32(float* out, long long* cyc, int ite
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
-template <int PER, int NE, int NC, int NM>
+template <int PER, int NE, int NC, int NM, int NACC = 4>
 void run32(const char* what) {
   float* out; long long* cyc;
   hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 256 * 8 * 8);
@@ -97,10 +97,10 @@ void run32(const char* what) {
   for (int waves = 1; waves <= 2; ++waves) {
     const int threads = 256 * waves;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    mix32<PER, NE, NC, NM><<<256, threads>>>(out, cyc, iters);
+    mix32<PER, NE, NC, NM, NACC><<<256, threads>>>(out, cyc, iters);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    mix32<PER, NE, NC, NM><<<256, threads>>>(out, cyc, iters);
+    mix32<PER, NE, NC, NM, NACC><<<256, threads>>>(out, cyc, iters);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -113,7 +113,7 @@ void run32(const char* what) {
   hipFree(out); hipFree(cyc);
 }
 
-template <int PER, int NE, int NC, int NM>
+template <int PER, int NE, int NC, int NM, int NACC = 8>
 void run(const char* what) {
   float* out; long long* cyc;
   hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 256 * 8 * 8);
@@ -122,10 +122,10 @@ void run(const char* what) {
   for (int waves = 1; waves <= 2; ++waves) {
     const int threads = 256 * waves;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    mix<PER, NE, NC, NM><<<256, threads>>>(out, cyc, iters);
+    mix<PER, NE, NC, NM, NACC><<<256, threads>>>(out, cyc, iters);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    mix<PER, NE, NC, NM><<<256, threads>>>(out, cyc, iters);
+    mix<PER, NE, NC, NM, NACC><<<256, threads>>>(out, cyc, iters);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -170,5 +170,20 @@ int main() {
   run32<8, 16, 8, 6>("8 MFMA32 : 16 exp + 8 cvt + 6 mul");
   run32<16, 32, 16, 11>("16 MFMA32 : 32 exp + 16 cvt + 11 mul");
   run32<36, 64, 32, 25>("36 MFMA32 : 64 exp + 32 cvt + 25 mul (whole tile clustered)");
+  printf("\n---- dependent MFMAs: the same accumulator every 1 / 2 / 4 (/ 8) MFMAs, bare and with one VALU filler per MFMA ----\n");
+  run<1, 0, 0, 0, 1>("16x16x32, 1 accumulator (back-to-back dependent)");
+  run<1, 0, 0, 0, 2>("16x16x32, 2 accumulators");
+  run<1, 0, 0, 0, 4>("16x16x32, 4 accumulators");
+  run<1, 1, 0, 0, 1>("16x16x32, 1 accumulator  + 1 exp per MFMA");
+  run<1, 1, 0, 0, 2>("16x16x32, 2 accumulators + 1 exp per MFMA");
+  run<1, 1, 0, 0, 4>("16x16x32, 4 accumulators + 1 exp per MFMA");
+  run<1, 0, 0, 1, 1>("16x16x32, 1 accumulator  + 1 mul per MFMA");
+  run<1, 0, 0, 1, 2>("16x16x32, 2 accumulators + 1 mul per MFMA");
+  run32<1, 0, 0, 0, 1>("32x32x16, 1 accumulator (back-to-back dependent)");
+  run32<1, 0, 0, 0, 2>("32x32x16, 2 accumulators");
+  run32<1, 2, 1, 1, 1>("32x32x16, 1 accumulator  + attention mix");
+  run32<1, 2, 1, 1, 2>("32x32x16, 2 accumulators + attention mix");
+  run32<1, 0, 0, 1, 1>("32x32x16, 1 accumulator  + 1 mul per MFMA");
+  run32<1, 0, 0, 1, 2>("32x32x16, 2 accumulators + 1 mul per MFMA");
   return 0;
 }
