@@ -101,8 +101,10 @@ END_NEW = '''  };
   if constexpr (DMA) __syncthreads();              // drain the tail transfers before the ring is reused (fallback pass) or the workgroup ends'''
 
 
-def pipe_experiment(schedule):
+def pipe_experiment(schedule, no_rowsum=False):
+    G.NO_ROWSUM = no_rowsum
     body = G.emit(G.generate(schedule))
+    G.NO_ROWSUM = False
     prefix = PIPE_PREFIX.replace("@NAME@", schedule).replace("@BODY@", body)
     return [("ovg_attn16.h", "\n  int since_barrier = 0;\n", prefix), ("ovg_attn16.h", HEAD_OLD, HEAD_NEW), ("ovg_attn16.h", LOOP_OLD, LOOP_NEW),
             ("ovg_attn16.h", PV_OLD, PV_NEW), ("ovg_attn16.h", END_OLD, END_NEW)]
@@ -164,6 +166,7 @@ EXPERIMENTS = {
     "pipe_v2": pipe_experiment("v2"),
     "pipe_v3": pipe_experiment("v3"),
     "pipe_v1_prio": pipe_experiment("v1") + prio_experiment("young"),
+    "pipe_v2_norowsum": pipe_experiment("v2", no_rowsum=True),   # TIMING ONLY (garbage results): the price of the 8 row-sum MFMAs per tile
     "pipe_v4": pipe_experiment("v4"),
     "pipe_v5": pipe_experiment("v5"),
     "attn32_w1": attn32_experiment("w1"),

@@ -20,6 +20,7 @@ err == 0 against variant 57).
 import sys
 
 QB = 4
+NO_ROWSUM = False
 
 
 def mfma_stream():
@@ -252,7 +253,10 @@ def emit(stream):
                 out.append("PB_MFMA_ACC(t[%d][%d], K[%d][1], qf[%d][1]); PB_SPLIT(%d, %d);" % (kt, qb, kt, qb, kt, qb))
             elif x[0] == "L":
                 u, qb = x[1], x[2]
-                out.append("PB_PACK(%d, %d); PB_MFMA_ACC(lacc[%d], ones, pf[%d][%d]);" % (u, qb, qb, u, qb))
+                if NO_ROWSUM:      # timing-only experiment: what would the launch cost WITHOUT the 8 row-sum MFMAs (results are garbage: l stays 0)
+                    out.append("PB_PACK(%d, %d);" % (u, qb))
+                else:
+                    out.append("PB_PACK(%d, %d); PB_MFMA_ACC(lacc[%d], ones, pf[%d][%d]);" % (u, qb, qb, u, qb))
             else:
                 u, qb, dt = x[1], x[2], x[3]
                 out.append("PB_MFMA_ACC(o[%d][%d], V[%d][%d], pf[%d][%d]);" % (qb, dt, u, dt, u, qb))
