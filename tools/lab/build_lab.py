@@ -6,6 +6,7 @@ compiled with the product's flags (omnivggt-official_amd/build.py). Unchanged tr
 product's on the same box and checks the outputs. Nothing here is imported by the package, the tests or bench.py.
 
     python tools/lab/build_lab.py [name ...]         (default: all experiments)
+    python tools/lab/build_lab.py --apply-to-product pipe_v2      (promote an experiment: patches csrc/ in place; see apply_to_product)
 """
 import os
 import shutil
@@ -237,7 +238,23 @@ def build(name):
     return so, sorted(dirty)
 
 
+def apply_to_product(name):
+    """Write an experiment's substitutions into the PRODUCT sources (omnivggt-official_amd/csrc). For experiments that have earned it
+    (pipe_v2: bit-identical outputs, +1.3 ... 5 %): afterwards rebuild (`__graft_entry__.build()`), re-take the traffic passes
+    (tools/retake_traffic_r03.sh -> profiles/traffic.json; the attention source digest changes) and run the whole `-m gpu` suite."""
+    for f, old, new in EXPERIMENTS[name]:
+        assert not f.startswith("+"), "experiments that add lab-only files stay in the lab"
+        p = os.path.join(B.CSRC, f)
+        s = open(p).read()
+        assert s.count(old) == 1, "anchor not found exactly once in %s: %r" % (f, old[:60])
+        open(p, "w").write(s.replace(old, new))
+        print("patched", os.path.relpath(p, ROOT))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) == 3 and sys.argv[1] == "--apply-to-product":
+        apply_to_product(sys.argv[2])
+        sys.exit(0)
     names = sys.argv[1:] or list(EXPERIMENTS)
     for n in names:
         so, dirty = build(n)
