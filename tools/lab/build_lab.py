@@ -6,7 +6,7 @@ compiled with the product's flags (omnivggt-official_amd/build.py). Unchanged tr
 product's on the same box and checks the outputs. Nothing here is imported by the package, the tests or bench.py.
 
     python tools/lab/build_lab.py [name ...]         (default: all experiments)
-    python tools/lab/build_lab.py --apply-to-product pipe_v2      (promote an experiment: patches csrc/ in place; see apply_to_product)
+    python tools/lab/build_lab.py --apply-to-product pipe_v2_q2   (promote an experiment: patches csrc/ in place; see apply_to_product)
 """
 import os
 import shutil
@@ -36,17 +36,21 @@ PIPE_PREFIX = r'''
 #define PB_MFMA_ACC(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 #define PB_SPLIT(kt, qb) do { s[kt][qb][0] = t[kt][qb][0]; s[kt][qb][1] = t[kt][qb][1]; s[kt][qb][2] = t[kt][qb][2]; s[kt][qb][3] = t[kt][qb][3]; } while (0)
 #define PB_PACK(u, qb) pf[u][qb] = u32x4{pw[u][qb][0], pw[u][qb][1], pw[u][qb][2], pw[u][qb][3]}
-  constexpr bool PIPE = SM == 2 && QB == 4 && DMA > 0 && !VSUM && std::is_same<T, bf16_t>::value;
+  constexpr bool PIPE = SM == 2 && (QB == 4 || (QB == 2 && @HAVE_Q2@)) && DMA > 0 && !VSUM && std::is_same<T, bf16_t>::value;
   auto pipe_tile = [&](int slot) {
     if constexpr (PIPE) {
       const uint32_t kb = lds_base + slot * SLOT_B + frag_row;
       const uint32_t ka0 = kb + coff0, ka1 = kb + coff1;
       const uint32_t va0 = kb + KT_B + (((0 + g) ^ sx) << 4), va1 = kb + KT_B + (((4 + g) ^ sx) << 4);
-      u32x4 K[4][2], V[2][4], pf[2][4];
-      f32x4 t[4][4];
-      float s[4][4][4];
-      uint32_t pw[2][4][4];
+      u32x4 K[4][2], V[2][4], pf[2][QB];
+      f32x4 t[4][QB];
+      float s[4][QB][4];
+      uint32_t pw[2][QB][4];
+      if constexpr (QB == 4) {
 @BODY@
+      } else {
+@BODY2@
+      }
     }
   };
 #undef PB_DSR
@@ -102,11 +106,13 @@ END_NEW = '''  };
   if constexpr (DMA) __syncthreads();              // drain the tail transfers before the ring is reused (fallback pass) or the workgroup ends'''
 
 
-def pipe_experiment(schedule, no_rowsum=False):
+def pipe_experiment(schedule, no_rowsum=False, schedule_q2=None):
     G.NO_ROWSUM = no_rowsum
     body = G.emit(G.generate(schedule))
     G.NO_ROWSUM = False
-    prefix = PIPE_PREFIX.replace("@NAME@", schedule).replace("@BODY@", body)
+    body2 = G.emit(G.generate(schedule_q2)) if schedule_q2 else ""
+    prefix = (PIPE_PREFIX.replace("@NAME@", schedule + (" / " + schedule_q2 if schedule_q2 else "")).replace("@BODY@", body)
+              .replace("@BODY2@", body2).replace("@HAVE_Q2@", "true" if schedule_q2 else "false"))
     return [("ovg_attn16.h", "\n  int since_barrier = 0;\n", prefix), ("ovg_attn16.h", HEAD_OLD, HEAD_NEW), ("ovg_attn16.h", LOOP_OLD, LOOP_NEW),
             ("ovg_attn16.h", PV_OLD, PV_NEW), ("ovg_attn16.h", END_OLD, END_NEW)]
 
@@ -168,6 +174,7 @@ EXPERIMENTS = {
     "pipe_v3": pipe_experiment("v3"),
     "pipe_v1_prio": pipe_experiment("v1") + prio_experiment("young"),
     "pipe_v2_norowsum": pipe_experiment("v2", no_rowsum=True),   # TIMING ONLY (garbage results): the price of the 8 row-sum MFMAs per tile
+    "pipe_v2_q2": pipe_experiment("v2", schedule_q2="v2q2"),     # + the 128-row kernels (tail launch, frame / DINOv2 attention at 64 views)
     "pipe_v4": pipe_experiment("v4"),
     "pipe_v5": pipe_experiment("v5"),
     "attn32_w1": attn32_experiment("w1"),

@@ -73,6 +73,12 @@ SCHEDULES = {
                       25: [("V", 0, 0)], 27: [("V", 0, 1)], 29: [("V", 0, 2)], 31: [("V", 0, 3)],
                       44: [("V", 1, 0)], 46: [("V", 1, 1)], 48: [("V", 1, 2)], 50: [("V", 1, 3)]}),
     # v5: smaller clusters: MFMA groups of 8 / 5, bursts of ~64 cycles
+    # v2q2: the v2 idea for the 128-row kernels (QB = 2: 36 MFMAs, 32 exps, 16 converts per tile; the tail launch of the 64-view plan and the
+    # frame-local / DINOv2 attention at 64 views): one exp per MFMA as soon as the hazard distance allows
+    "v2q2": dict(qb=2, exp=lambda m: 1 if m >= 5 else 0, cvt=lambda m: 1 if m >= 9 else 0,
+                 reads={1: [("K", 2, 0)], 3: [("K", 2, 1)], 5: [("K", 3, 0)], 7: [("K", 3, 1)],
+                        9: [("V", 0, 0)], 11: [("V", 0, 1)], 13: [("V", 0, 2)], 15: [("V", 0, 3)],
+                        19: [("V", 1, 0)], 21: [("V", 1, 1)], 23: [("V", 1, 2)], 25: [("V", 1, 3)]}),
     "v5": dict(exp=lambda m: {15: 8, 19: 8, 23: 8, 27: 8, 31: 4, 36: 6, 41: 6, 46: 6, 51: 6, 56: 4}.get(m, 0),
                cvt=lambda m: {31: 8, 36: 4, 41: 4, 46: 4, 51: 4, 56: 4, 61: 4}.get(m, 0),
                reads={3: [("K", 2, 0)], 5: [("K", 2, 1)], 11: [("K", 3, 0)], 13: [("K", 3, 1)],
@@ -102,7 +108,9 @@ def cvt_sources(u, qb, w):
 
 
 def generate(name):
+    global QB
     sch = SCHEDULES[name]
+    QB = sch.get("qb", 4)
     mf = mfma_stream()
     stream = []          # (kind, payload) in issue order
     lds_queue = []       # outstanding reads, oldest first

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--names", nargs="+", default=None)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--mode", default="global", choices=["global", "frame"], help="global: 16 heads x (S x 1374) tokens; frame: S x 16 heads x 1374 tokens")
     ap.add_argument("--solo", action="store_true", help="time only the named builds (no control build beside them): for rocprofv3 passes, where "
                     "kernels of the same name and grid from two builds would be merged")
     ap.add_argument("--zero", action="store_true", help="zero-filled q / k / v: the same instruction stream at far lower switching power -- if the "
@@ -60,7 +61,7 @@ def main():
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     g = torch.Generator().manual_seed(0)
     for S in args.views:
-        BH, n = 16, S * 1374
+        BH, n = (16, S * 1374) if args.mode == "global" else (S * 16, 1374)
         q, k, vt = ops.alloc_qkv(BH, n, n, dt, DEV)
         q[:, :n] = (torch.randn(BH, n, 64, generator=g) * 1.3).to(dt).to(DEV)
         k[:, :n] = torch.randn(BH, n, 64, generator=g).to(dt).to(DEV)
@@ -73,7 +74,7 @@ def main():
         outs, errs = {}, {}
         for nm, v in list(combos):
             use(nm)
-            o = torch.zeros(n, 1024, device=DEV, dtype=dt)
+            o = torch.zeros((BH // 16) * n, 1024, device=DEV, dtype=dt)
             try:
                 ops.flash_attn(q, [(k, vt, n)], n, dt, out=o, variant=v)
             except L.OvgError as e:                     # a variant this build does not have (e.g. the lab kernels in the control build)
@@ -101,7 +102,7 @@ def main():
         base = statistics.median(times[(names[0], args.variants[0])]) if (names[0], args.variants[0]) in times else float("nan")
         for c in combos:
             ms = statistics.median(times[c])
-            print(("ZERO DATA " if args.zero else "") + "S=%-3d %-14s variant %-2d median %8.4f ms (min %8.4f)  %7.1f TFLOP/s  %5.1f%% of 2.5PF  vs control/plan %+6.2f%%  err_vs_baseline=%.2e  bits==control: %s"
+            print(("ZERO DATA " if args.zero else "") + ("frame " if args.mode == "frame" else "") + "S=%-3d %-14s variant %-2d median %8.4f ms (min %8.4f)  %7.1f TFLOP/s  %5.1f%% of 2.5PF  vs control/plan %+6.2f%%  err_vs_baseline=%.2e  bits==control: %s"
                   % (S, c[0], c[1], ms, min(times[c]), flop / ms / 1e9, flop / ms / 1e9 / 25.0, (base / ms - 1) * 100, errs[c], same[c]), flush=True)
         del q, k, vt, outs
         torch.cuda.empty_cache()
