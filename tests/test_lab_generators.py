@@ -42,3 +42,20 @@ def test_pinned_32x32x16_body_schedules_verify(schedule):
     for a1 in range(2):
         regs = sorted(r for w in range(4) for (_, _, r) in G.cvt_sources(0, a1, 0, w))
         assert regs == [4 * a1 + b for b in range(4)] + [4 * a1 + 8 + b for b in range(4)]
+
+
+def test_lab_experiments_still_anchor_in_the_product_sources():
+    """tools/lab/build_lab.py patches COPIES of csrc/ by exact text substitution: every anchor of every experiment must occur exactly
+    once in the current product sources, in the order the experiment applies them -- otherwise the lab (and the promotion of an
+    experiment with --apply-to-product) has silently rotted after an edit of the kernels."""
+    import build_lab as BL
+    csrc = BL.B.CSRC
+    for name, subs in BL.EXPERIMENTS.items():
+        text = {}
+        for f, old, new in subs:
+            if f.startswith("+"):
+                continue
+            if f not in text:
+                text[f] = open(os.path.join(csrc, f)).read()
+            assert text[f].count(old) == 1, (name, f, old[:70])
+            text[f] = text[f].replace(old, new)
