@@ -2,6 +2,7 @@
 """Benchmark of the OmniVGGT aggregator hot path on MI355X (contract: see the task prompt).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--views S] [--dtype bf16|f16|f32]
+        (N > 1 without a launcher around it: the script starts its own N ranks -- self_launch -- and returns their exit code)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -140,6 +141,39 @@ def synthetic_inputs(S, device, seed=1234, aux=False):
     return dict(images=images.to(device), extrinsics=ext.to(device), intrinsics=K.to(device), depth=depth.to(device), mask=mask.to(device))
 
 
+def launch_command(n, argv, port, script=None):
+    """The command line `python bench.py --gpus N` re-executes itself under: torch's elastic launcher, one rank per GPU on this
+    node, rendezvous on 127.0.0.1 (the container hostname may not resolve) at `port`; argv is forwarded verbatim."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n)), "--master-addr", "127.0.0.1",
+            "--master-port", str(int(port)), script or os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv, script=None, timeout=None):
+    """Run N ranks of this script (launch_command) and return the job's exit code. The ranks inherit stdout / stderr: rank 0's ONE
+    JSON line is the only thing on stdout (the launcher's own chatter goes to stderr), so `python bench.py --gpus N` behaves
+    like the N = 1 call. A rank that dies makes the launcher tear the others down and return non-zero; a rank that hangs is
+    the per-rank watchdog's business (it prints a partial line and exits 3)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL / cross-process device memory on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, int(n)))))
+    cmd = launch_command(n, argv, free_port(), script)
+    sys.stderr.write("[bench launcher] %s\n" % " ".join(cmd))
+    sys.stderr.flush()
+    try:
+        return subprocess.run(cmd, env=env, timeout=timeout).returncode
+    except subprocess.TimeoutExpired:
+        sys.stderr.write("[bench launcher] timed out after %s s\n" % timeout)
+        return 124
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,18 +201,23 @@ def main():
                     "(BASELINE configs[4] with --views 128 --dtype f16)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher of N ranks (one process per GPU) and hand back their verdict
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (one process per GPU)" % args.gpus)
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     result = {"metric": "frames/sec (518^2, S views) aggregator hot path", "value": None, "unit": "frames/s", "n_gpus": world,
               "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic"}
     wd = Watchdog(rank, world, args.watchdog_s, result)
+    wd.stage("library load (a stale in-tree .so is rebuilt under a file lock: one rank compiles, the others wait)")
+    wd.timeout = max(wd.timeout, 900.0) if args.watchdog_s > 0 else wd.timeout
     L.require_gpu()
+    L.load()
+    wd.timeout = float(args.watchdog_s)
     if os.environ.get("OVG_FORCE_DEVICE"):      # debugging aid: several ranks on one GPU (only if the RCCL build accepts it)
         local = int(os.environ["OVG_FORCE_DEVICE"])
     torch.cuda.set_device(local)
@@ -231,12 +270,15 @@ def main():
     def timed_steps(step, steps, warmup):
         """EXACTLY `steps` timed forwards between barrier + synchronize on both sides; MAX over ranks."""
         agg.enable_attention_events(steps * agg.depth * 4)   # live HIP-event timing of every global-attention launch
+        if agg.fallback_counter is None:
+            agg.enable_fallback_counter(dev)                 # speculative-softmax telemetry: workgroups that re-ran (one atomic each)
         for i in range(warmup):
             wd.stage("warm-up step %d/%d" % (i + 1, warmup))
             step()
             if world > 1:
                 torch.cuda.synchronize()                     # warm-up only: a hang shows up in THIS stage, not three stages later
         agg.reset_attention_events()
+        agg.read_fallback_counter()                          # zero it for the timed region (synchronises; outside the timing)
         wd.stage("barrier before the timed region")
         barrier()
         wd.stage("timed region: %d steps" % steps)
@@ -248,14 +290,15 @@ def main():
         dt = time.perf_counter() - t0
         ms, fl = agg.attention_event_times(), agg.attention_event_flops()
         agg.disable_attention_events()
-        dt, attn_ms = reduce_max([dt, sum(ms)])
-        return dt, attn_ms, sum(fl), len(ms)
+        fb = agg.read_fallback_counter() or 0
+        dt, attn_ms, fb = reduce_max([dt, sum(ms), float(fb)])
+        return dt, attn_ms, sum(fl), len(ms), int(fb)
 
     def measure(S, steps, warmup):
         """Time `steps` aggregator forwards on S views; returns the result dict (rank-reduced)."""
         step = make_step(S)
         n_local = S // world + (1 if rank < S % world else 0)
-        dt, attn_ms, attn_flop, launches = timed_steps(step, steps, warmup)
+        dt, attn_ms, attn_flop, launches, fallbacks = timed_steps(step, steps, warmup)
         f_total, _ = agg_flops(S)
         achieved = attn_flop / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.dtype]
@@ -277,7 +320,10 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kernel_name(args.dtype, n_local * P_TOK, S * P_TOK) + " (global cross-view attention, D=64)",
                          "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                          "flop_per_launch": attn_flop / max(launches, 1), "avg_launch_ms": round(attn_ms / max(launches, 1), 4),
-                         "launches_timed": launches},
+                         "launches_timed": launches,
+                         # bf16: workgroups of ALL attention launches of the timed steps (DINOv2 + frame + global) whose speculative
+                         # softmax pass failed its check and re-ran with the lazy-rescale body (max over ranks); 0 = the fast path always paid
+                         "fallback_workgroups": fallbacks if args.dtype == "bf16" else None},
         }
         if shard is not None:
             res["comm"] = comm_report(step, S, steps, dt / steps * 1e3)

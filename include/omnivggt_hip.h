@@ -15,8 +15,8 @@
  *   - every pointer is a DEVICE pointer owned by the caller and must stay valid
  *     until the stream reaches the call; 16-byte aligned unless noted.
  *   - `dtype` selects the storage/MFMA input type of activations and weights:
- *     OVG_BF16 / OVG_F16 (throughput modes, f32 accumulate) or OVG_F32
- *     (parity mode, exact-f32 MFMA).  The residual stream, LayerNorm
+ *     OVG_BF16 / OVG_F16 (throughput modes, f32 accumulate), OVG_F32
+ *     (parity mode, exact-f32 MFMA) or OVG_F16X2 (split-f16 parity mode, see the enum).  The residual stream, LayerNorm
  *     statistics, softmax statistics, biases, LayerScale gammas, q/k-norm
  *     affine parameters and the RoPE table are always f32.
  *   - thread-safe for distinct streams; the library holds NO mutable state: every tuning choice is either
@@ -41,10 +41,20 @@ extern "C" {
  * 5-6: camera head entry; 16-bit V^T rows in the PV fragment order (LDS-DMA staged attention)
  * 7: split-KV workspace SIZES travel with the pointers (ws_part_bytes / ws_lse_bytes: an undersized workspace is OVG_E_ARG
  *    instead of an out-of-bounds write), ovg_camera_tables (camera-modality injection tables built on the device), OVG_F32 in the DPT-head
- *    entries, ovg_attn_plan_out.main_rows / tail_q_tile (the tail split of long attention launches is part of the queryable plan) */
-#define OVG_ABI_VERSION 7
+ *    entries, ovg_attn_plan_out.main_rows / tail_q_tile (the tail split of long attention launches is part of the queryable plan)
+ * 8: OVG_F16X2 -- the split-f16 compute mode ("f32x": every 16-bit operand tensor is a PAIR of f16 planes hi + lo, products run as
+ *    three f16 MFMAs hi*hi + hi*lo + lo*hi with f32 accumulation: ~2^-22 per product instead of 2^-8 (bf16) / 2^-11 (f16) at
+ *    a third of the 16-bit MFMA rate; the `*_lo` pointers below, NULL / ignored for the other dtypes);
+ *    ovg_attn_params.fallback_count / ovg_block_params.attn_fallback_count (telemetry of the speculative bf16 softmax) */
+#define OVG_ABI_VERSION 8
 
-enum { OVG_BF16 = 0, OVG_F16 = 1, OVG_F32 = 2 };
+enum { OVG_BF16 = 0, OVG_F16 = 1, OVG_F32 = 2,
+       /* split-f16 ("f32x", the <= 1e-4 mode with throughput): a value x is stored as hi = f16(x) (saturated at +-65504) in the tensor the
+        * ordinary pointer names and lo = f16(x - hi) in a second f16 tensor of the same shape / strides named by the matching `*_lo` pointer.
+        * x ~ hi + lo to 2^-22 relative (|x| >= 2^-3; absolute 2^-25 below, where lo is an f16 subnormal). A GEMM / attention contraction over
+        * such operands is hi*hi + hi*lo + lo*hi on the f16 MFMA (f16 x f16 products are exact in f32) with f32 accumulation, the dropped
+        * lo*lo term is 2^-22 relative. Everything that is f32 in the other modes stays f32. */
+       OVG_F16X2 = 3 };
 
 enum {
   OVG_OK = 0,
@@ -77,6 +87,7 @@ typedef struct {
   void* y; int64_t ldy;
   const float* weight; const float* bias;
   int64_t rows; float eps; int dtype; int out_f32;
+  void* y_lo;                    /* OVG_F16X2: lo plane of y (same ldy) */
 } ovg_layernorm_params;
 int ovg_layernorm(const ovg_layernorm_params*, void* stream);
 
@@ -113,6 +124,8 @@ typedef struct {
   /* PATCH */
   const float* table; int64_t p0; int64_t p1; int64_t row_off;
   int tile;   /* OVG_TILE_AUTO (shape heuristic), OVG_TILE_128 or OVG_TILE_256 (16-bit dtypes, N % 256 == 0); an impossible request is OVG_E_ARG */
+  /* OVG_F16X2: lo planes of x / w (same ldx / ldw) and, for 16-bit outputs (STORE / GELU without out_f32), of y (same ldy) */
+  const void* x_lo; const void* w_lo; void* y_lo;
 } ovg_linear_params;
 int ovg_linear(const ovg_linear_params*, void* stream);
 
@@ -145,6 +158,8 @@ typedef struct {
   float q_scale;
   int part;   /* 0 = q,k,v; 1 = k and v only; 2 = q only (sharded path: K/V first, all-gather || Q) */
   int tile;   /* OVG_TILE_* as in ovg_linear_params */
+  /* OVG_F16X2: lo planes (same shapes / strides as their hi tensors) */
+  const void* x_lo; const void* w_lo; void* q_lo; void* k_lo; void* vt_lo;
 } ovg_qkv_params;
 int ovg_qkv(const ovg_qkv_params*, void* stream);
 
@@ -158,7 +173,9 @@ int ovg_qkv(const ovg_qkv_params*, void* stream);
  *   seg[i].k [BH, nk_pad_i, 64], seg[i].vt [BH, 64, nk_pad_i] (16-bit: columns in the ovg_qkv order above), nk_i valid keys
  *   out [B*nq, H*64] token-major (row = (bh/H)*nq + n, col = (bh%H)*64 + d), ld = ldo
  * ------------------------------------------------------------------ */
-typedef struct { const void* k; const void* vt; int64_t nk; int64_t nk_pad; } ovg_kv_segment;
+typedef struct { const void* k; const void* vt; int64_t nk; int64_t nk_pad;
+                 const void* k_lo; const void* vt_lo;   /* OVG_F16X2: lo planes of k / vt (same shapes) */
+} ovg_kv_segment;
 typedef struct {
   const void* q; int64_t nq; int64_t nq_pad;
   ovg_kv_segment seg[OVG_MAX_SEG]; int nseg;
@@ -183,6 +200,13 @@ typedef struct {
    * Units of one (batch entry, split) run next to each other, so the K / V^T range an XCD streams shrinks by kv_splits.
    * ws_part_bytes / ws_lse_bytes: sizes of the two buffers; a call whose plan needs more than it was given is OVG_E_ARG. */
   int kv_splits; void* ws_part; float* ws_lse; int64_t ws_part_bytes; int64_t ws_lse_bytes;
+  /* OVG_F16X2: lo planes of q and out (same shapes / strides). That mode runs one launch of 256-row tiles: no split-KV, no kv_heads /
+   * head-major output (OVG_E_UNSUPPORTED), lse is available. */
+  const void* q_lo; void* out_lo;
+  /* Telemetry of the speculative softmax (OVG_BF16 default kernels): optional DEVICE counter; every workgroup whose speculative pass
+   * failed its verification and re-ran with the lazy-rescale body adds 1 (one atomic per such workgroup; nothing is written otherwise,
+   * the caller zeroes it). The result is exact either way -- the counter says how often the fast path did not pay. NULL = not counted. */
+  uint32_t* fallback_count;
 } ovg_attn_params;
 int ovg_flash_attn(const ovg_attn_params*, void* stream);
 
@@ -225,6 +249,7 @@ typedef struct {
   const void* fc1_w; const float* fc1_b;   /* dtype [4096,1024] */
   const void* fc2_w; const float* fc2_b;   /* dtype [1024,4096] */
   const float* ls2;
+  const void* qkv_w_lo; const void* proj_w_lo; const void* fc1_w_lo; const void* fc2_w_lo;   /* OVG_F16X2: lo planes of the four GEMM weights */
 } ovg_block_weights;
 
 typedef struct {
@@ -257,6 +282,9 @@ typedef struct {
   int gemm_tile;       /* OVG_TILE_* forwarded to the four GEMMs of the block (tests force a tile; 0 in production) */
   /* optional split-KV workspace of the block's attention launch (ovg_attn_params.ws_part / ws_lse + their sizes; NULL = never split) */
   void* ws_attn_part; float* ws_attn_lse; int attn_kv_splits; int64_t ws_attn_part_bytes; int64_t ws_attn_lse_bytes;
+  /* OVG_F16X2: lo planes of the six scratch tensors (same sizes as their hi tensors; ovg_block_workspace_bytes reports the size of ONE plane) */
+  void* ws_xn_lo; void* ws_q_lo; void* ws_k_lo; void* ws_vt_lo; void* ws_attn_lo; void* ws_hid_lo;
+  uint32_t* attn_fallback_count;   /* forwarded to ovg_attn_params.fallback_count of the block's attention launch (NULL = not counted) */
 } ovg_block_params;
 /* whole block */
 int ovg_block_forward(const ovg_block_params*, void* stream);
@@ -276,6 +304,7 @@ int ovg_block_workspace_bytes(const ovg_block_params*, ovg_block_workspace* out)
 typedef struct {
   const float* src; int64_t lds; void* dst; int64_t ldd;
   int64_t rows; int64_t k; int64_t k_pad; int dtype;
+  void* dst_lo;                  /* OVG_F16X2: lo plane (same ldd) */
 } ovg_pack_weights_params;
 int ovg_pack_weights(const ovg_pack_weights_params*, void* stream);
 
@@ -293,6 +322,7 @@ typedef struct {
   float mean[3]; float std[3];
   const double* depth_stats;  /* mode1: [B][2] = {sum, count}; V = B*views_per_batch */
   int64_t views_per_batch;
+  void* out_lo;               /* OVG_F16X2: lo plane of out */
 } ovg_im2col_params;
 int ovg_im2col(const ovg_im2col_params*, void* stream);
 

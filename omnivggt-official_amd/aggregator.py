@@ -178,6 +178,7 @@ class BlockRunner:
         p.attn_variant = int(getattr(self.knobs, "attn_variant", 0))
         p.gemm_tile = int(getattr(self.knobs, "gemm_tile", 0))
         p.attn_kv_splits = int(getattr(self.knobs, "attn_kv_splits", 0))
+        p.attn_fallback_count = L.ptr(getattr(self.knobs, "fallback_counter", None))
         if p.attn_kv_splits != 1 and hasattr(ws, "split_ws"):
             part, lse = ws.split_ws(p.attn_variant, p.attn_kv_splits)
             p.ws_attn_part, p.ws_attn_lse = L.ptr(part), L.ptr(lse)
@@ -243,6 +244,7 @@ class ZeroAggregator(nn.Module):
         self.attn_kv_splits = 0     # ovg_attn_params.kv_splits: 0 = library decides per launch, 1 = never split
         self.max_workspaces = 4     # scratch shapes kept alive (frame + global of the two most recent geometries)
         self.shard = None           # set by sharding.ViewSharding for the multi-GPU path
+        self.fallback_counter = None    # enable_fallback_counter(): device int32 the attention launches count their re-run workgroups into
         self._packed = None
         self._ws = {}
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
@@ -281,6 +283,23 @@ class ZeroAggregator(nn.Module):
 
     def disable_attention_events(self):
         self._events, self._event_i, self._event_flop = [], 0, []
+
+    # ------------------------------------------------------------------
+    # telemetry of the speculative bf16 softmax (ovg_attn_params.fallback_count): how many workgroups of the attention launches since
+    # the last reset failed the verification of their speculative pass and re-ran with the lazy-rescale body (results are exact either way)
+    def enable_fallback_counter(self, device):
+        self.fallback_counter = torch.zeros(1, dtype=torch.int32, device=device)
+        return self.fallback_counter
+
+    def read_fallback_counter(self, reset=True):
+        """Workgroups that paid the second pass since the last reset (synchronises the device); None when not enabled."""
+        c = getattr(self, "fallback_counter", None)
+        if c is None:
+            return None
+        n = int(c.item())
+        if reset:
+            c.zero_()
+        return n
 
     def invalidate(self):
         self._packed = None

@@ -453,6 +453,7 @@ extern "C" int ovg_flash_attn(const ovg_attn_params* p, void* stream) {
   }
   if ((reinterpret_cast<uintptr_t>(p->q) | reinterpret_cast<uintptr_t>(p->out)) & 15) return OVG_E_ARG;
   if (p->lse && (reinterpret_cast<uintptr_t>(p->lse) & 3)) return OVG_E_ARG;
+  if (p->fallback_count && (reinterpret_cast<uintptr_t>(p->fallback_count) & 3)) return OVG_E_ARG;
   if (p->kv_splits < 0 || p->kv_splits > OVG_MAX_SEG) return OVG_E_ARG;
   if ((p->ws_part && (reinterpret_cast<uintptr_t>(p->ws_part) & 15)) || (p->ws_lse && (reinterpret_cast<uintptr_t>(p->ws_lse) & 3))) return OVG_E_ARG;
   if (p->kv_splits > 1 && (p->dtype == OVG_F32 || p->variant == 1 || p->variant == 2)) return OVG_E_UNSUPPORTED;   // the baseline kernel never splits

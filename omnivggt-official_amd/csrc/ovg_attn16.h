@@ -302,9 +302,53 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
     }
   }
 
+  // ---- order-pinned tile body of the bf16 speculative pass (r04; generator + rationale: tools/gen_attn_body.py) -----------------
+  // Every MFMA / v_exp_f32 / v_cvt_pk_bf16_f32 / ds_read_b128 / s_waitcnt of a FULL tile is one `asm volatile` statement: hipcc keeps
+  // their order and only allocates the registers. One exp per MFMA, evenly spread (schedule v2; v2q2 for QB = 2), instead of hipcc's
+  // [32 MFMA][32 exp + 16 cvt][40 MFMA + 32 exp] clusters: +1.3 ... 2.3 % at 64 views, +5 % at 8 views, bit-identical results
+  // (same arithmetic, same order per accumulator). The hazard distances hipcc no longer inserts are checked by the generator.
+#define PB_DSR(d, a, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(d) : "v"(a))
+#define PB_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")")
+#define PB_NOP() asm volatile("s_nop 0")
+#define PB_EXP(x) asm volatile("v_exp_f32 %0, %0" : "+v"(x))
+#define PB_CVT(d, a, b) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
+#define PB_MFMA_NEW(d, a, b, c) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c))
+#define PB_MFMA_ACC(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define PB_SPLIT(kt, qb) do { s[kt][qb][0] = t[kt][qb][0]; s[kt][qb][1] = t[kt][qb][1]; s[kt][qb][2] = t[kt][qb][2]; s[kt][qb][3] = t[kt][qb][3]; } while (0)
+#define PB_PACK(u, qb) pf[u][qb] = u32x4{pw[u][qb][0], pw[u][qb][1], pw[u][qb][2], pw[u][qb][3]}
+  constexpr bool PIPE = SM == 2 && (QB == 4 || QB == 2) && DMA > 0 && !VSUM && std::is_same<T, bf16_t>::value;
+  auto pipe_tile = [&](int slot) {
+    if constexpr (PIPE) {
+      const uint32_t kb = lds_base + slot * SLOT_B + frag_row;
+      const uint32_t ka0 = kb + coff0, ka1 = kb + coff1;
+      const uint32_t va0 = kb + KT_B + (((0 + g) ^ sx) << 4), va1 = kb + KT_B + (((4 + g) ^ sx) << 4);
+      u32x4 K[4][2], V[2][4], pf[2][QB];
+      f32x4 t[4][QB];
+      float s[4][QB][4];
+      uint32_t pw[2][QB][4];
+      if constexpr (QB == 4) {
+#include "ovg_attn16_body_q4.inc"
+      } else {
+#include "ovg_attn16_body_q2.inc"
+      }
+    }
+  };
+#undef PB_DSR
+#undef PB_LGKM
+#undef PB_NOP
+#undef PB_EXP
+#undef PB_CVT
+#undef PB_MFMA_NEW
+#undef PB_MFMA_ACC
+#undef PB_SPLIT
+#undef PB_PACK
+
   int since_barrier = 0;
   int buf = 0;                                     // register path: LDS buffer of tile j; DMA path: ring slot of tile j
-  for (int j = 0; j < total_tiles; ++j) {
+  // the loop body as a generic lambda, instantiated twice -- the order-pinned body for the leading FULL tiles of a single-segment
+  // launch, the compiler-scheduled body for the rest (the masked last tile; every tile of a multi-segment launch) -- so that the
+  // hot loop holds ONE body (with both in one loop hipcc joins their register assignments with ~50 copies and spills O)
+  auto tile_iter = [&](int j, auto use_pipe) {
     const bool more = (j + 1) < total_tiles;
     if constexpr (DMA) {
       dma_issue(buf >= BARP ? buf - BARP : buf - BARP + DMA);   // tile j + B + 1 -> slot (j - B) % R
@@ -316,6 +360,9 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
     const int kv0 = ctile * BC;
 
     f32x4 s[4][QB];
+    if constexpr (decltype(use_pipe)::value) {
+      pipe_tile(buf);
+    } else {
     qk_tile(kl, s, kv0 + BC > c_nk, kv0);          // the tail branch doubles as the scheduling fence (header)
     if constexpr (SM == 2) {
 #pragma unroll
@@ -343,6 +390,7 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
     }
     pv_step(vl, 0, s[0], s[1]);
     pv_step(vl, 1, s[2], s[3]);
+    }
 
     if (++ctile == c_ntiles) {
       ctile = 0; ++cseg;
@@ -362,7 +410,16 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
       __syncthreads();
       buf ^= 1;
     }
+  };
+  int j_all = 0;
+  if constexpr (PIPE) {
+    // full tiles in front of the first masked one: single segment, tiles tile0 .. ; tile t is full iff (t + 1) * BC <= nk
+    int n_full = p.nseg == 1 ? (int)(p.seg[0].nk / BC) - tile0 : 0;
+    n_full = n_full < total_tiles ? n_full : total_tiles;
+    for (; j_all < n_full; ++j_all) tile_iter(j_all, std::true_type{});
+    asm volatile("s_nop 15\n\ts_nop 15");     // asm MFMA results -> VALU / builtin readers behind the loop (hipcc does not see the hazard)
   }
+  for (; j_all < total_tiles; ++j_all) tile_iter(j_all, std::false_type{});
   if constexpr (DMA) __syncthreads();              // drain the tail transfers before the ring is reused (fallback pass) or the workgroup ends
   if constexpr (VSUM) {
 #pragma unroll
@@ -438,7 +495,11 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params
 #pragma unroll
         for (int r = 0; r < 4; ++r) bad = bad || attn16::nonfinite(o[qb][dt][r]);
     }
-    if (__syncthreads_or(bad ? 1 : 0)) attn16::run_tiles<T, QB, WAVES, 0, VSUM, DMA>(p, lds, bh, q0, t0, nt, o, lacc, negm);
+    if (__syncthreads_or(bad ? 1 : 0)) {
+      // telemetry (ovg_attn_params.fallback_count): one atomic per workgroup that pays the second pass; the result is exact either way
+      if (p.fallback_count != nullptr && threadIdx.x == 0) atomicAdd(p.fallback_count, 1u);
+      attn16::run_tiles<T, QB, WAVES, 0, VSUM, DMA>(p, lds, bh, q0, t0, nt, o, lacc, negm);
+    }
   }
 
   attn16::write_out<T, QB>(p, o, lacc, negm, bh, q0, sp, splits);

@@ -10,11 +10,11 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libomnivggt_hip.so")
 
-OVG_BF16, OVG_F16, OVG_F32 = 0, 1, 2
+OVG_BF16, OVG_F16, OVG_F32, OVG_F16X2 = 0, 1, 2, 3
 EPI_STORE, EPI_GELU, EPI_RES, EPI_PATCH = 0, 1, 2, 3
 OVG_MAX_SEG = 8
 KV_TILE = 64
-ABI_VERSION = 7
+ABI_VERSION = 8
 TILE_AUTO, TILE_128, TILE_256 = 0, 1, 2
 TILE_R02_EPILOGUE, TILE_128X, TILE_256X = 16, 17, 18      # A/B flag (r02 epilogue forms) OR-ed onto a tile selector
 
@@ -25,14 +25,15 @@ vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
 class LayerNormParams(C.Structure):
     _fields_ = [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("weight", vp), ("bias", vp),
-                ("rows", i64), ("eps", f32), ("dtype", i32), ("out_f32", i32)]
+                ("rows", i64), ("eps", f32), ("dtype", i32), ("out_f32", i32), ("y_lo", vp)]
 
 
 class LinearParams(C.Structure):
     _fields_ = [("x", vp), ("ldx", i64), ("w", vp), ("ldw", i64), ("bias", vp), ("y", vp), ("ldy", i64),
                 ("M", i64), ("N", i64), ("K", i64), ("dtype", i32), ("epilogue", i32), ("out_f32", i32),
                 ("res", vp), ("ldres", i64), ("gamma", vp), ("inject", vp), ("inj_period", i64),
-                ("table", vp), ("p0", i64), ("p1", i64), ("row_off", i64), ("tile", i32)]
+                ("table", vp), ("p0", i64), ("p1", i64), ("row_off", i64), ("tile", i32),
+                ("x_lo", vp), ("w_lo", vp), ("y_lo", vp)]
 
 
 class QkvParams(C.Structure):
@@ -40,18 +41,19 @@ class QkvParams(C.Structure):
                 ("M", i64), ("seq", i64), ("nq_pad", i64), ("nk_pad", i64), ("dtype", i32),
                 ("qk_norm", i32), ("qn_w", vp), ("qn_b", vp), ("kn_w", vp), ("kn_b", vp), ("qk_eps", f32),
                 ("rope", i32), ("rope_cos", vp), ("rope_sin", vp), ("max_pos", i32),
-                ("tokens_per_view", i64), ("grid_w", i32), ("n_special", i32), ("q_scale", f32), ("part", i32), ("tile", i32)]
+                ("tokens_per_view", i64), ("grid_w", i32), ("n_special", i32), ("q_scale", f32), ("part", i32), ("tile", i32),
+                ("x_lo", vp), ("w_lo", vp), ("q_lo", vp), ("k_lo", vp), ("vt_lo", vp)]
 
 
 class KvSegment(C.Structure):
-    _fields_ = [("k", vp), ("vt", vp), ("nk", i64), ("nk_pad", i64)]
+    _fields_ = [("k", vp), ("vt", vp), ("nk", i64), ("nk_pad", i64), ("k_lo", vp), ("vt_lo", vp)]
 
 
 class AttnParams(C.Structure):
     _fields_ = [("q", vp), ("nq", i64), ("nq_pad", i64), ("seg", KvSegment * OVG_MAX_SEG), ("nseg", i32),
                 ("out", vp), ("ldo", i64), ("BH", i64), ("dtype", i32), ("variant", i32),
                 ("kv_heads", i32), ("out_bh_stride", i64), ("lse", vp), ("kv_splits", i32), ("ws_part", vp), ("ws_lse", vp),
-                ("ws_part_bytes", i64), ("ws_lse_bytes", i64)]
+                ("ws_part_bytes", i64), ("ws_lse_bytes", i64), ("q_lo", vp), ("out_lo", vp), ("fallback_count", vp)]
 
 
 class AttnPlanOut(C.Structure):
@@ -67,7 +69,8 @@ class BlockWeights(C.Structure):
     _fields_ = [("n1_w", vp), ("n1_b", vp), ("qkv_w", vp), ("qkv_b", vp),
                 ("qn_w", vp), ("qn_b", vp), ("kn_w", vp), ("kn_b", vp),
                 ("proj_w", vp), ("proj_b", vp), ("ls1", vp), ("n2_w", vp), ("n2_b", vp),
-                ("fc1_w", vp), ("fc1_b", vp), ("fc2_w", vp), ("fc2_b", vp), ("ls2", vp)]
+                ("fc1_w", vp), ("fc1_b", vp), ("fc2_w", vp), ("fc2_b", vp), ("ls2", vp),
+                ("qkv_w_lo", vp), ("proj_w_lo", vp), ("fc1_w_lo", vp), ("fc2_w_lo", vp)]
 
 
 class BlockParams(C.Structure):
@@ -81,7 +84,9 @@ class BlockParams(C.Structure):
                 ("extra", KvSegment * OVG_MAX_SEG), ("nseg_extra", i32), ("local_seg_index", i32),
                 ("attn_variant", i32), ("qkv_part", i32), ("ev_attn_start", vp), ("ev_attn_stop", vp),
                 ("skip_attention", i32), ("gemm_tile", i32), ("ws_attn_part", vp), ("ws_attn_lse", vp), ("attn_kv_splits", i32),
-                ("ws_attn_part_bytes", i64), ("ws_attn_lse_bytes", i64)]
+                ("ws_attn_part_bytes", i64), ("ws_attn_lse_bytes", i64),
+                ("ws_xn_lo", vp), ("ws_q_lo", vp), ("ws_k_lo", vp), ("ws_vt_lo", vp), ("ws_attn_lo", vp), ("ws_hid_lo", vp),
+                ("attn_fallback_count", vp)]
 
 
 class BlockWorkspace(C.Structure):
@@ -89,13 +94,13 @@ class BlockWorkspace(C.Structure):
 
 
 class PackWeightsParams(C.Structure):
-    _fields_ = [("src", vp), ("lds", i64), ("dst", vp), ("ldd", i64), ("rows", i64), ("k", i64), ("k_pad", i64), ("dtype", i32)]
+    _fields_ = [("src", vp), ("lds", i64), ("dst", vp), ("ldd", i64), ("rows", i64), ("k", i64), ("k_pad", i64), ("dtype", i32), ("dst_lo", vp)]
 
 
 class Im2colParams(C.Structure):
     _fields_ = [("img", vp), ("img2", vp), ("out", vp), ("k_pad", i64), ("V", i64), ("C", i32), ("Hpx", i32),
                 ("Wpx", i32), ("dtype", i32), ("mode", i32), ("mean", f32 * 3), ("std", f32 * 3),
-                ("depth_stats", vp), ("views_per_batch", i64)]
+                ("depth_stats", vp), ("views_per_batch", i64), ("out_lo", vp)]
 
 
 class DepthStatsParams(C.Structure):

@@ -287,6 +287,40 @@ def test_bench_watchdog_dumps_stacks_prints_the_partial_line_and_exits(tmp_path)
     assert r1.returncode == 3 and r1.stdout.strip() == "" and "[rank 1/2]" in r1.stderr
 
 
+def test_bench_self_launch_starts_n_ranks_and_propagates_the_exit_code(tmp_path):
+    """`python bench.py --gpus N` (N > 1) with no launcher around it must start its own N ranks (round-3 review: the scaling leg
+    could not start). bench.self_launch re-executes the script under torch.distributed.run on 127.0.0.1 with a free port, argv
+    forwarded verbatim; rank 0's line is the only stdout; the job's exit code comes back (0 / the failing rank's)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "2"], 29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-5] == os.path.join(ROOT, "bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    script = tmp_path / "fake_bench.py"
+    script.write_text("import os, sys, json\n"
+                      "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+                      "assert os.environ['MASTER_ADDR'] == '127.0.0.1' and os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'\n"
+                      "if r == 0: print(json.dumps({'n_gpus': w, 'argv': sys.argv[1:]}), flush=True)\n"
+                      "sys.exit(7 if ('--fail' in sys.argv and r == 1) else 0)\n")
+    code = ("import sys; sys.path.insert(0, %r); import bench\n"
+            "sys.exit(bench.self_launch(2, sys.argv[1:], script=%r, timeout=240))\n") % (ROOT, str(script))
+    ok = subprocess.run([sys.executable, "-c", code, "--gpus", "2", "--views", "8"], capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    line = json.loads(ok.stdout.strip().splitlines()[-1])
+    assert line == {"n_gpus": 2, "argv": ["--gpus", "2", "--views", "8"]} and len(ok.stdout.strip().splitlines()) == 1
+    bad = subprocess.run([sys.executable, "-c", code, "--fail"], capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0
+    # the real script takes that road when WORLD_SIZE is unset: on this CPU-only host the ranks fail loudly (no HIP device)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--watchdog-s", "60"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert "[bench launcher]" in r.stderr and "torch.distributed.run" in r.stderr
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "no HIP device visible" in r.stderr
+
+
 def test_committed_traffic_record_matches_the_attention_sources():
     """profiles/traffic.json (what bench.py prints as roofline.traffic) is tied to the sha256 of the attention sources it was measured
     on; the committed record must describe the committed kernels -- editing ovg_attn.hip / ovg_attn16.h / ovg_common.h without

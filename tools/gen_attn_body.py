@@ -1,21 +1,25 @@
-"""Generator of the ORDER-PINNED attention tile body (lab experiment, round 3).
+"""Generator of the ORDER-PINNED tile body of the bf16 speculative attention kernel (csrc/ovg_attn16.h, run_tiles<SM = 2>).
 
-The shipped speculative body (ovg_attn16.h, run_tiles<SM = 2>) leaves the instruction order to hipcc, which clusters it:
-[32 QK^T MFMAs][32 v_exp + 16 v_cvt_pk][40 PV MFMAs with the other 32 exps in front]. Every attempt to make hipcc interleave
-(sched_group_barrier, sched_barrier fences, source-level pipelining) lost to register spills or to its own clustering. Here
-the order is pinned instead: every MFMA, v_exp_f32, v_cvt_pk_bf16_f32, ds_read_b128 and s_waitcnt of a full (unmasked) tile
-is ONE `asm volatile` statement -- hipcc never reorders volatile asm statements against each other, but still allocates the
-registers (checked: no copies, exps run in place on the MFMA result registers, the converts write straight into the P
-fragment tuples). What hipcc no longer does for us, and this generator therefore checks on the emitted stream:
+    python tools/gen_attn_body.py --write     regenerate csrc/ovg_attn16_body_q4.inc (schedule v2) and _q2.inc (schedule v2q2)
+    python tools/gen_attn_body.py --check     exit 1 if the committed .inc files differ from what the generator emits
+    python tools/gen_attn_body.py <schedule>  print one schedule's body (the round-3 lab schedules are kept for reference)
+
+Left to hipcc, the instruction order of a tile clusters: [32 QK^T MFMAs][32 v_exp + 16 v_cvt_pk][40 PV MFMAs with the other 32
+exps in front]; every attempt to make hipcc interleave (sched_group_barrier, sched_barrier fences, source-level pipelining) lost
+to register spills or to its own clustering. Here the order is pinned instead: every MFMA, v_exp_f32, v_cvt_pk_bf16_f32,
+ds_read_b128 and s_waitcnt of a full (unmasked) tile is ONE `asm volatile` statement -- hipcc never reorders volatile asm
+statements against each other, but still allocates the registers (checked: no copies, exps run in place on the MFMA result
+registers, the converts write straight into the P fragment tuples). What hipcc no longer does for us, and this generator
+therefore checks on the emitted stream (verify()):
   * MFMA result -> VALU read needs 8 wait states on gfx950 (4-pass XDL op); we demand >= 8 instructions in between;
   * v_exp (transcendental) result -> v_cvt_pk read: >= 2 instructions in between;
   * v_cvt_pk result -> MFMA B operand: >= 2 instructions in between;
   * asm ds_reads are invisible to hipcc's s_waitcnt insertion: the generator tracks the in-order LDS return queue and emits
     the counted s_waitcnt lgkmcnt(n) in front of the first consumer of every fragment.
-Same arithmetic, same operation order per accumulator as the shipped body -> bit-identical results (the lab run checks
-err == 0 against variant 57).
-
-    python tools/lab/gen_pipe_body.py <schedule> > body.inc        schedules: see SCHEDULES below
+Same arithmetic, same operation order per accumulator as the compiler-scheduled body (which still runs the masked last tile and
+every tile of a multi-segment launch) -> bit-identical results. Measured in the round-3 lab (profiles/r03_attn_lab_*.txt,
+history: tools/history/r03/lab): schedule v2 (one exp per MFMA, evenly spread) +1.3...2.3 % at 64 views, +5 % at 8 views;
+v2q2 the same order for the 128-row kernels (tail launch, frame-local / DINOv2 attention).
 """
 import sys
 
@@ -278,8 +282,37 @@ def summary(stream):
     return n
 
 
+PRODUCT = {"ovg_attn16_body_q4.inc": "v2", "ovg_attn16_body_q2.inc": "v2q2"}
+
+
+def product_text(schedule):
+    st = generate(schedule)
+    n = summary(st)
+    head = ("// GENERATED by tools/gen_attn_body.py (schedule %s: %d MFMA, %d v_exp_f32, %d v_cvt_pk, %d ds_read_b128, %d counted waits, %d s_nop) -- do not edit;\n"
+            "// hazard distances and LDS wait counts are verified by the generator (tests/test_attn_body_generator.py re-checks this file against it).\n"
+            % (schedule, n.get("MFMA", 0), n.get("EXP", 0), n.get("CVT", 0), n.get("READ", 0), n.get("WAIT", 0), n.get("NOP", 0)))
+    return head + emit(st) + "\n"
+
+
+def product_paths():
+    import os
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "omnivggt-official_amd", "csrc")
+    return {os.path.join(csrc, f): sch for f, sch in PRODUCT.items()}
+
+
 if __name__ == "__main__":
-    name = sys.argv[1] if len(sys.argv) > 1 else "v1"
-    st = generate(name)
-    sys.stderr.write("schedule %s: %r\n" % (name, summary(st)))
+    arg = sys.argv[1] if len(sys.argv) > 1 else "--check"
+    if arg in ("--write", "--check"):
+        bad = 0
+        for path, sch in product_paths().items():
+            text = product_text(sch)
+            if arg == "--write":
+                open(path, "w").write(text)
+                print("wrote", path)
+            elif (not __import__("os").path.exists(path)) or open(path).read() != text:
+                print("STALE:", path)
+                bad = 1
+        sys.exit(bad)
+    st = generate(arg)
+    sys.stderr.write("schedule %s: %r\n" % (arg, summary(st)))
     print(emit(st))
