@@ -108,7 +108,7 @@ def attention_source_digest():
     """sha256 over the sources that define the attention kernels and their launch plan (what profiles/traffic.json is tied to)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("ovg_attn.hip", "ovg_attn16.h", "ovg_common.h"):
+    for f in ("ovg_attn.hip", "ovg_attn16.h", "ovg_attn16_body_q4.inc", "ovg_attn16_body_q2.inc", "ovg_common.h"):
         with open(os.path.join(ROOT, "omnivggt-official_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
