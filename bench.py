@@ -52,17 +52,20 @@ from omnivggt_official_amd import lib as L, weights  # noqa: E402
 from omnivggt_official_amd.model import OmniVGGT  # noqa: E402
 
 P_TOK, C = 1374, 1024
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}     # MI355X_MICROARCH.md, dense MFMA
-DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+# MI355X_MICROARCH.md, dense MFMA. f32x (split-f16, three f16 MFMAs per product): a third of the f16 peak per ALGORITHMIC flop
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f32x": 2500.0 / 3.0}
+DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f32x": L.F32X}
 KERNEL_NAME = {"bf16": "attn16_kernel<bf16,QB=4,WAVES=%d,MODE=0> (speculative anchored softmax + verified fallback; K/V^T tiles by LDS-DMA; %d-row q tiles)",
                "f16": "attn16_kernel<f16,QB=4,WAVES=%d,MODE=1> (lazy-rescale online softmax; K/V^T tiles by LDS-DMA; %d-row q tiles)",
-               "f32": "attn_kernel<float,QB=1> (exact-f32 MFMA 16x16x4, classic online softmax)"}
+               "f32": "attn_kernel<float,QB=1> (exact-f32 MFMA 16x16x4, classic online softmax)",
+               "f32x": "attn16_kernel<f16,QB=2,WAVES=8,MODE=1,X3> (split-f16: q / K / V^T / P as (hi, lo) f16 planes, three f16 MFMAs per product, "
+                       "lazy-rescale online softmax, exact f32 row sums; K / V^T tiles by LDS-DMA; 256-row q tiles)"}
 
 
 def kernel_name(dtype_name, n_q, n_k):
     """Name of the global-attention kernel the library's launch plan picks for this shape (ovg_attn_plan)."""
-    if dtype_name == "f32":
-        return KERNEL_NAME["f32"]
+    if dtype_name in ("f32", "f32x"):
+        return KERNEL_NAME[dtype_name]
     from omnivggt_official_amd import ops
     plan = ops.attn_plan(16, n_q, [n_k], DT[dtype_name])
     name = KERNEL_NAME[dtype_name] % (min(plan["q_tile"] // 64, 8), plan["q_tile"])
@@ -470,7 +473,8 @@ def parity_block(agg, dev, args, view_counts):
     reference CPU path: tests/test_gpu_aggregator.py) on the bench's own inputs and sizes. Per sampled layer:
     max-rel = max|a-b| / max|b| and rms-rel = rms(a-b) / rms(b) over a strided sample of the (S,1374,2048) tokens."""
     dt16 = agg.compute_dtype
-    out = {"reference": "same library in compute_dtype=float32 (exact-f32 MFMA; <= 1e-4 of the reference CPU path at S <= 3, tests/test_gpu_aggregator.py)",
+    out = {"mode_checked": repr(dt16).replace("torch.", ""),
+           "reference": "same library in compute_dtype=float32 (exact-f32 MFMA; <= 1e-4 of the reference CPU path at S <= 3, tests/test_gpu_aggregator.py)",
            "layers": list(PARITY_LAYERS), "sample": "tokens[:, :, ::7, ::8] of each sampled layer"}
 
     def sample(outs):

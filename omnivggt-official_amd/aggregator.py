@@ -98,10 +98,10 @@ class Workspace:
         self.BH = (M // seq) * HEADS
         if share is not None:
             self.xn, self.attn, self.hid = share.xn, share.attn, share.hid
-        else:
-            self.xn = torch.empty(M, C, device=device, dtype=dtype)
-            self.attn = torch.empty(M, C, device=device, dtype=dtype)
-            self.hid = torch.empty(M, 4 * C, device=device, dtype=dtype)
+        else:                                   # split-f16 mode (L.F32X): ops.HiLo pairs of f16 planes
+            self.xn = ops.empty_like_dtype((M, C), dtype, device)
+            self.attn = ops.empty_like_dtype((M, C), dtype, device)
+            self.hid = ops.empty_like_dtype((M, 4 * C), dtype, device)
         rows = seq if kv_rows is None else kv_rows
         self.q, self.k, self.vt = ops.alloc_qkv(self.BH, rows, rows, dtype, device)
         self.device, self._split = device, {}
@@ -114,7 +114,7 @@ class Workspace:
         key = (variant, kv_splits)
         if key not in self._split:
             plan = (ops.attn_plan(self.BH, self.seq, [self.seq], self.dtype, variant, kv_splits, nq_pad=self.q.shape[1])
-                    if (self.dtype != torch.float32 and kv_splits != 1) else {"splits": 1})
+                    if (self.dtype in (torch.bfloat16, torch.float16) and kv_splits != 1) else {"splits": 1})
             self._split[key] = ops.alloc_split_ws(plan, self.device)
         return self._split[key]
 
@@ -137,11 +137,15 @@ class BlockRunner:
 
         def grab(name, dt):
             src = sd["%s.%s" % (prefix, name)].detach()
-            if name in self._GEMM and dt != torch.float32 and src.dtype == torch.float32:
-                t[name] = ops.pack_weights(src.to(device), dt)       # ovg_pack_weights: f32 checkpoint -> compute dtype
+            if name in self._GEMM and dt is not torch.float32 and src.dtype == torch.float32:
+                t[name] = ops.pack_weights(src.to(device), dt)       # ovg_pack_weights: f32 checkpoint -> compute dtype (split-f16: a HiLo pair)
+            elif L.is_split(dt):
+                raise L.OvgError("the split-f16 mode packs its (hi, lo) weight planes from f32 masters: load the f32 checkpoint")
             else:
                 t[name] = src.to(device=device, dtype=dt).contiguous()
-            return L.ptr(t[name])
+            return L.ptr(ops.hi_lo(t[name])[0])
+
+        lo = lambda name: L.ptr(ops.hi_lo(t[name])[1])
 
         w = L.BlockWeights()
         w.n1_w, w.n1_b = grab("norm1.weight", torch.float32), grab("norm1.bias", torch.float32)
@@ -155,6 +159,7 @@ class BlockRunner:
         w.fc1_w, w.fc1_b = grab("mlp.fc1.weight", dtype), grab("mlp.fc1.bias", torch.float32)
         w.fc2_w, w.fc2_b = grab("mlp.fc2.weight", dtype), grab("mlp.fc2.bias", torch.float32)
         w.ls2 = grab("ls2.gamma", torch.float32)
+        w.qkv_w_lo, w.proj_w_lo, w.fc1_w_lo, w.fc2_w_lo = lo("attn.qkv.weight"), lo("attn.proj.weight"), lo("mlp.fc1.weight"), lo("mlp.fc2.weight")
         self.tensors, self.weights = t, w
         if rope:
             if rope_tables is None:
@@ -173,8 +178,10 @@ class BlockRunner:
         p.tokens_per_view, p.grid_w, p.n_special = tokens_per_view, grid_w, n_special
         if inject is not None:
             p.inject, p.inj_period = L.ptr(inject), inj_period
-        p.ws_xn, p.ws_q, p.ws_k, p.ws_vt, p.ws_attn, p.ws_hid = (L.ptr(ws.xn), L.ptr(ws.q), L.ptr(ws.k), L.ptr(ws.vt),
-                                                                  L.ptr(ws.attn), L.ptr(ws.hid))
+        for name in ("xn", "q", "k", "vt", "attn", "hid"):
+            hi, lo = ops.hi_lo(getattr(ws, name))
+            setattr(p, "ws_" + name, L.ptr(hi))
+            setattr(p, "ws_%s_lo" % name, L.ptr(lo))
         p.attn_variant = int(getattr(self.knobs, "attn_variant", 0))
         p.gemm_tile = int(getattr(self.knobs, "gemm_tile", 0))
         p.attn_kv_splits = int(getattr(self.knobs, "attn_kv_splits", 0))
@@ -238,7 +245,7 @@ class ZeroAggregator(nn.Module):
             nn.init.zeros_(a.bias)
         self.depth_patch_embed = _ConvProj(2, embed_dim)
         self.pose_hidden_dim = pose_hidden_dim
-        self.compute_dtype = compute_dtype
+        self.compute_dtype = L.F32X if compute_dtype == "f32x" else compute_dtype
         self.attn_variant = 0       # ovg_attn_params.variant of every attention call (0 = library default); read per call
         self.gemm_tile = 0          # OVG_TILE_* forced on the block GEMMs (tests); 0 = shape heuristic
         self.attn_kv_splits = 0     # ovg_attn_params.kv_splits: 0 = library decides per launch, 1 = never split
@@ -338,9 +345,11 @@ class ZeroAggregator(nn.Module):
         return pk[key]
 
     def set_compute_dtype(self, dtype):
-        if dtype not in (torch.bfloat16, torch.float16, torch.float32):
-            raise ValueError("compute dtype must be bf16, f16 or f32")
-        if dtype != self.compute_dtype:
+        if dtype == "f32x":
+            dtype = L.F32X
+        if dtype not in (torch.bfloat16, torch.float16, torch.float32) and dtype is not L.F32X:
+            raise ValueError("compute dtype must be bf16, f16, f32 or the split-f16 mode lib.F32X ('f32x')")
+        if dtype is not self.compute_dtype:
             self.compute_dtype = dtype
             self.invalidate()
 
@@ -351,7 +360,7 @@ class ZeroAggregator(nn.Module):
         device = torch.device(device)
         if device.type == "cuda" and device.index is None:          # "cuda" and "cuda:<current>" are the same pack
             device = torch.device("cuda", torch.cuda.current_device())
-        if sd is None and self._packed is not None and self._packed["device"] == device and self._packed["dtype"] == self.compute_dtype:
+        if sd is None and self._packed is not None and self._packed["device"] == device and self._packed["dtype"] is self.compute_dtype:
             return self._packed
         L.require_gpu()
         dt = self.compute_dtype
@@ -369,7 +378,7 @@ class ZeroAggregator(nn.Module):
         pk["global"] = [BlockRunner(sd, "global_blocks.%d" % i, dt, device, True, True, 1e-5, rope, knobs=self) for i in range(self.depth)]
 
         def conv_as_gemm(w, k_pad):          # Conv2d(k=14, s=14) weight [1024, C_in, 14, 14] -> GEMM rows [1024, k_pad]
-            if w.dim() == 2 and w.shape[1] == k_pad and w.dtype == dt:      # already packed (load_packed)
+            if w.dim() == 2 and w.shape[1] == k_pad and w.dtype is dt:      # already packed (load_packed)
                 return w.detach().to(device).contiguous()
             return ops.pack_weights(w.detach().to(device), dt, k_pad=k_pad)
 
@@ -416,6 +425,8 @@ class ZeroAggregator(nn.Module):
         """Install export_packed() output (any device) as this aggregator's packed weights; the module's own parameters are
         not touched (they may stay on the meta device: forward() only reads the packed form)."""
         want = next(v.dtype for k, v in sd.items() if k.endswith("global_blocks.0.attn.qkv.weight"))
+        if L.is_split(self.compute_dtype):
+            raise ValueError("packed files hold one 16-bit plane per weight; the split-f16 mode packs from the f32 checkpoint")
         if want != self.compute_dtype:
             raise ValueError("packed weights are %s but compute_dtype is %s" % (want, self.compute_dtype))
         self._packed = None
@@ -430,7 +441,7 @@ class ZeroAggregator(nn.Module):
         if ws is None:
             while len(self._ws) >= max(2, int(self.max_workspaces)):
                 self._ws.pop(next(iter(self._ws)))                  # dicts keep insertion order: first = least recently used
-            share = next((o for (m2, _, dt2, dv2), o in self._ws.items() if m2 == M and dt2 == self.compute_dtype and dv2 == str(device)), None)
+            share = next((o for (m2, _, dt2, dv2), o in self._ws.items() if m2 == M and dt2 is self.compute_dtype and dv2 == str(device)), None)
             ws = Workspace(M, seq, self.compute_dtype, device, share=share)
         self._ws[key] = ws                                           # (re)insert as most recently used
         return ws
@@ -521,6 +532,8 @@ class ZeroAggregator(nn.Module):
         if not images.is_cuda:
             raise L.OvgError("ZeroAggregator.forward needs HIP device tensors: there is no CPU fallback")
         if self.shard is not None:
+            if L.is_split(self.compute_dtype):
+                raise L.OvgError("the split-f16 mode (f32x) is single-GPU: the view-sharded exchange forms move one 16-bit plane per tensor")
             return self.shard.forward(self, images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index)
         device = images.device
         pk = self.pack(device)

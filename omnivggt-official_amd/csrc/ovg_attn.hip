@@ -368,13 +368,13 @@ Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
   return pl;
 }
 
-template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false, int DMA = 0>
+template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false, int DMA = 0, bool X3 = false>
 int launch_attn16(const ovg_attn_params& p, const Plan16& pl, hipStream_t st, int64_t row0 = 0, int64_t row1 = -1) {   // q rows [row0, row1) (default: all)
   constexpr int BQ = 16 * QB * WAVES;
   if (row1 < 0) row1 = p.nq;
   const int nqt = (int)((row1 - row0 + BQ - 1) / BQ);
   const dim3 grid((unsigned)(p.BH * nqt * pl.splits)), block(64 * WAVES);
-  OVG_LAUNCH((attn16_kernel<T, QB, WAVES, MODE, OCC, VSUM, DMA>), grid, block, 0, st, p, nqt, pl.total_tiles, pl.splits, pl.per_split, (int)row0);
+  OVG_LAUNCH((attn16_kernel<T, QB, WAVES, MODE, OCC, VSUM, DMA, X3>), grid, block, 0, st, p, nqt, pl.total_tiles, pl.splits, pl.per_split, (int)row0);
   OVG_CHECK_LAUNCH();
   if (pl.splits > 1) {
     const int64_t total = p.BH * p.nq * 8;
@@ -440,6 +440,15 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
   }
 }
 
+// split-f16 mode (OVG_F16X2): one launch of 256-row tiles -- 8 waves x 2 q blocks, lazy-rescale softmax, a 3-slot LDS-DMA ring of
+// [K hi | V^T hi | K lo | V^T lo] tiles (96 KB, one workgroup per CU), three f16 MFMAs per product
+int dispatch_x3(const ovg_attn_params& p, hipStream_t st) {
+  Plan16 pl{};
+  pl.variant = 90; pl.bq = 256; pl.splits = 1; pl.total_tiles = total_key_tiles(p); pl.per_split = pl.total_tiles;
+  pl.main_rows = p.nq; pl.tail_bq = 0;
+  return launch_attn16<f16_t, 2, 8, 1, 2, true, 3, true>(p, pl, st);
+}
+
 }  // namespace
 
 extern "C" int ovg_flash_attn(const ovg_attn_params* p, void* stream) {
@@ -463,6 +472,13 @@ extern "C" int ovg_flash_attn(const ovg_attn_params* p, void* stream) {
     case OVG_BF16: return dispatch16<bf16_t>(*p, st);
     case OVG_F16: return dispatch16<f16_t>(*p, st);
     case OVG_F32: return launch_attn<float, 1>(*p, st);
+    case OVG_F16X2: {
+      if (p->kv_splits > 1 || p->kv_heads > 0 || p->out_bh_stride > 0) return OVG_E_UNSUPPORTED;
+      if (!p->q_lo || !p->out_lo || ((reinterpret_cast<uintptr_t>(p->q_lo) | reinterpret_cast<uintptr_t>(p->out_lo)) & 15)) return OVG_E_ARG;
+      for (int i = 0; i < p->nseg; ++i)
+        if (!p->seg[i].k_lo || !p->seg[i].vt_lo || ((reinterpret_cast<uintptr_t>(p->seg[i].k_lo) | reinterpret_cast<uintptr_t>(p->seg[i].vt_lo)) & 15)) return OVG_E_ARG;
+      return dispatch_x3(*p, st);
+    }
     default: return OVG_E_DTYPE;
   }
 }
@@ -472,6 +488,7 @@ extern "C" int ovg_attn_plan(const ovg_attn_params* p, ovg_attn_plan_out* out) {
   for (int i = 0; i < p->nseg; ++i)
     if (p->seg[i].nk <= 0) return OVG_E_ARG;
   out->splits = 1; out->q_tile = 64; out->part_bytes = 0; out->lse_bytes = 0; out->main_rows = p->nq; out->tail_q_tile = 0;
+  if (p->dtype == OVG_F16X2) { out->q_tile = 256; return OVG_OK; }
   if (p->dtype != OVG_BF16 && p->dtype != OVG_F16) return p->dtype == OVG_F32 ? OVG_OK : OVG_E_DTYPE;
   const Plan16 pl = plan16(*p, p->dtype == OVG_BF16, true);
   if (pl.variant == 1 || pl.variant == 2) return OVG_OK;

@@ -99,29 +99,50 @@ OVG_DEV u32x4 pack2(const f32x4 a, const f32x4 b) {
   return r;
 }
 
+// P tile -> (hi, lo) f16 fragments of the split-f16 mode: hi = f16(p), lo = f16(p - hi); p <= 2^8 (lazy rescale), no saturation needed
+OVG_DEV void pack2_hilo(const f32x4 a, const f32x4 b, u32x4& hi, u32x4& lo) {
+  f16_t h[8], l[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = static_cast<f16_t>(a[i]); l[i] = static_cast<f16_t>(a[i] - static_cast<float>(h[i]));
+    h[4 + i] = static_cast<f16_t>(b[i]); l[4 + i] = static_cast<f16_t>(b[i] - static_cast<float>(h[4 + i]));
+  }
+  __builtin_memcpy(&hi, h, 16);
+  __builtin_memcpy(&lo, l, 16);
+}
+
 // One pass over all key tiles of all segments for the wave's QB x 16 query rows; leaves the un-normalised
 // O^T in o, the row sums in lacc (every register of lacc[qb] holds the full sum of row q0 + 16 qb + lane&15) and the
 // negated reference maximum in negm (P = exp2(s + negm)): log2 sum_k exp2(s) = log2(lacc) - negm.
 // (lds_dma16, the asm-issued LDS-DMA transfer the staging below uses, lives in ovg_common.h)
-template <typename T, int QB, int WAVES, int SM, bool VSUM = false, int DMA = 0>   // VSUM: row sums on the VALU (experiment, variant 31) instead of the ones-MFMA; DMA: 0 = register staging, R = 2 B + 1 (3, 5, 7, 9): K / V^T tiles by LDS-DMA into a ring of R slots, B + 1 tiles ahead, one workgroup barrier every B tiles
+// X3 (OVG_F16X2, the split-f16 parity mode; T = f16_t, SM = 0, VSUM, DMA): q, K and V^T are (hi, lo) plane pairs -- a ring slot holds
+// [K hi | V^T hi | K lo | V^T lo] -- and both contractions run three MFMAs per product into the same f32 accumulator, small terms first:
+//   S = K_lo Q_hi + K_hi Q_lo + K_hi Q_hi,   O += V_lo P_hi + V_hi P_lo + V_hi P_hi,   P = (hi, lo) split of exp2(S - m) in registers;
+// the row sums are exact f32 sums of P on the VALU (the matrix pipe is the bound here: 104 MFMAs against ~100 VALU per tile at QB = 2).
+template <typename T, int QB, int WAVES, int SM, bool VSUM = false, int DMA = 0, bool X3 = false>   // VSUM: row sums on the VALU (experiment, variant 31) instead of the ones-MFMA; DMA: 0 = register staging, R = 2 B + 1 (3, 5, 7, 9): K / V^T tiles by LDS-DMA into a ring of R slots, B + 1 tiles ahead, one workgroup barrier every B tiles
 OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int bh, const int q0, const int t_begin, const int total_tiles,
                        f32x4 (&o)[QB][4], f32x4 (&lacc)[QB], f32x4 (&negm)[QB]) {   // key tiles [t_begin, t_begin + total_tiles) of the flattened segment list
   constexpr int NT = 64 * WAVES;
   constexpr int RB = 128, KT_B = BC * RB, VT_B = OVG_D * RB, CPT = 512 / NT;
+  static_assert(!X3 || (DMA > 0 && VSUM && SM == 0 && std::is_same<T, f16_t>::value), "split-f16: f16 planes, LDS-DMA staging, lazy rescale, VALU row sums");
+  constexpr int PLANE_B = KT_B + VT_B;             // one plane of a ring slot: K tile + V^T tile
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int g = lane >> 4, lr = lane & 15;
   const int nq = (int)p.nq;
 
-  u32x4 qf[QB][2];
+  u32x4 qf[QB][2], ql[X3 ? QB : 1][2];
   {
     const unsigned char* qbase = static_cast<const unsigned char*>(p.q) + (int64_t)bh * p.nq_pad * RB;
+    const unsigned char* qbase_lo = static_cast<const unsigned char*>(p.q_lo) + (int64_t)bh * p.nq_pad * RB;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       int q = q0 + qb * 16 + lr; q = q < nq ? q : nq - 1;
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
+      for (int kk = 0; kk < 2; ++kk) {
         qf[qb][kk] = *reinterpret_cast<const u32x4*>(qbase + (int64_t)q * RB + (4 * kk + g) * 16);
+        if constexpr (X3) ql[qb][kk] = *reinterpret_cast<const u32x4*>(qbase_lo + (int64_t)q * RB + (4 * kk + g) * 16);
+      }
     }
   }
 #pragma unroll
@@ -144,7 +165,7 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
   //   their MFMA-heavy and exp-heavy phases stop coinciding). At the barrier after tile j - 1 (j = 0 mod B) the tiles j .. j + B - 1
   //   must have landed: with the transfers issued B + 1 tiles ahead that is "all but the newest tile" = vmcnt(NDMA). A slot is
   //   rewritten (tile j + B + 1 -> the slot of tile j - B) only after a barrier that follows the last read of tile j - B: R >= 2 B + 1.
-  constexpr int SLOT_B = KT_B + VT_B, NDMA = 2 * (8 / WAVES), BARP = DMA ? (DMA - 1) / 2 : 1;
+  constexpr int SLOT_B = (X3 ? 2 : 1) * PLANE_B, NDMA = (X3 ? 2 : 1) * 2 * (8 / WAVES), BARP = DMA ? (DMA - 1) / 2 : 1;
   static_assert(DMA == 0 || (DMA == 2 * BARP + 1 && BARP >= 1), "ring = 2 * barrier period + 1");
   u32x4 rk[DMA ? 1 : CPT], rv[DMA ? 1 : CPT];
   int k_goff[CPT], v_row[CPT], v_coff[CPT], k_loff[CPT], v_loff[CPT];
@@ -164,6 +185,9 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
   const unsigned char* kptr = static_cast<const unsigned char*>(p.seg[fseg].k) + ((int64_t)kvh * p.seg[fseg].nk_pad + (int64_t)ftile * BC) * RB;
   const unsigned char* vptr = static_cast<const unsigned char*>(p.seg[fseg].vt) + ((int64_t)kvh * OVG_D * p.seg[fseg].nk_pad + (int64_t)ftile * BC) * 2;
   int64_t vstride = p.seg[fseg].nk_pad * 2;       // bytes between V^T rows (d)
+  // split-f16: byte distance from the hi to the lo plane of the current segment's K / V^T
+  int64_t kdl = X3 ? static_cast<const unsigned char*>(p.seg[fseg].k_lo) - static_cast<const unsigned char*>(p.seg[fseg].k) : 0;
+  int64_t vdl = X3 ? static_cast<const unsigned char*>(p.seg[fseg].vt_lo) - static_cast<const unsigned char*>(p.seg[fseg].vt) : 0;
   const int seg0 = fseg, tile0 = ftile;
   auto next_tile = [&]() {                          // advance the fetch cursor (kptr / vptr / vstride) by one tile, across segments
     kptr += KT_B;
@@ -176,6 +200,10 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
         kptr = static_cast<const unsigned char*>(sg.k) + (int64_t)kvh * sg.nk_pad * RB;
         vptr = static_cast<const unsigned char*>(sg.vt) + (int64_t)kvh * OVG_D * sg.nk_pad * 2;
         vstride = sg.nk_pad * 2;
+        if constexpr (X3) {
+          kdl = static_cast<const unsigned char*>(sg.k_lo) - static_cast<const unsigned char*>(sg.k);
+          vdl = static_cast<const unsigned char*>(sg.vt_lo) - static_cast<const unsigned char*>(sg.vt);
+        }
       }
     }
   };
@@ -213,6 +241,12 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
     for (int i = 0; i < 8 / WAVES; ++i) lds_dma16(kptr + d_row[i] * RB + d_ch16[i], dst + i * 8 * RB);
 #pragma unroll
     for (int i = 0; i < 8 / WAVES; ++i) lds_dma16(vptr + d_row[i] * vstride + d_ch16[i], dst + KT_B + i * 8 * RB);
+    if constexpr (X3) {
+#pragma unroll
+      for (int i = 0; i < 8 / WAVES; ++i) lds_dma16(kptr + kdl + d_row[i] * RB + d_ch16[i], dst + PLANE_B + i * 8 * RB);
+#pragma unroll
+      for (int i = 0; i < 8 / WAVES; ++i) lds_dma16(vptr + vdl + d_row[i] * vstride + d_ch16[i], dst + PLANE_B + KT_B + i * 8 * RB);
+    }
     if (++issued < total_tiles) next_tile();
   };
 
@@ -240,6 +274,20 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
     for (int kt = 0; kt < 4; ++kt) {
       const u32x4 k0 = *reinterpret_cast<const u32x4*>(kl + kt * 2048 + frag_row + coff0);
       const u32x4 k1 = *reinterpret_cast<const u32x4*>(kl + kt * 2048 + frag_row + coff1);
+      if constexpr (X3) {
+        const u32x4 k0l = *reinterpret_cast<const u32x4*>(kl + PLANE_B + kt * 2048 + frag_row + coff0);
+        const u32x4 k1l = *reinterpret_cast<const u32x4*>(kl + PLANE_B + kt * 2048 + frag_row + coff1);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          s[kt][qb] = mma_c<T>(k0l, qf[qb][0], negm[qb]);
+          s[kt][qb] = mma_c<T>(k1l, qf[qb][1], s[kt][qb]);
+          s[kt][qb] = mma_c<T>(k0, ql[qb][0], s[kt][qb]);
+          s[kt][qb] = mma_c<T>(k1, ql[qb][1], s[kt][qb]);
+          s[kt][qb] = mma_c<T>(k0, qf[qb][0], s[kt][qb]);
+          s[kt][qb] = mma_c<T>(k1, qf[qb][1], s[kt][qb]);
+        }
+        continue;
+      }
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
         s[kt][qb] = mma_c<T>(k0, qf[qb][0], negm[qb]);
@@ -275,6 +323,27 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
   };
   // O^T += V^T P^T ; l += 1^T P^T for the 32-key step u (keys 32u + 16 (j>>2) + 4g + (j&3) in slot j)
   auto pv_step = [&](const unsigned char* vl, int u, const f32x4 (&sa)[QB], const f32x4 (&sb)[QB]) {
+    if constexpr (X3) {
+      u32x4 ph[QB], pl[QB];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        pack2_hilo(sa[qb], sb[qb], ph[qb], pl[qb]);
+        lacc[qb] += sa[qb] + sb[qb];                  // exact f32 row sums, lane-partial, reduced once after the loop
+      }
+      const int voff = ((4 * u + g) ^ sx) << 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const u32x4 vf = *reinterpret_cast<const u32x4*>(vl + dt * 2048 + frag_row + voff);
+        const u32x4 vfl = *reinterpret_cast<const u32x4*>(vl + PLANE_B + dt * 2048 + frag_row + voff);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          o[qb][dt] = mma_c<T>(vfl, ph[qb], o[qb][dt]);
+          o[qb][dt] = mma_c<T>(vf, pl[qb], o[qb][dt]);
+          o[qb][dt] = mma_c<T>(vf, ph[qb], o[qb][dt]);
+        }
+      }
+      return;
+    }
     u32x4 pf[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -355,7 +424,7 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
     } else {
       if (more) fetch();
     }
-    const unsigned char* kl = lds + buf * (KT_B + VT_B);
+    const unsigned char* kl = lds + buf * SLOT_B;
     const unsigned char* vl = kl + KT_B;
     const int kv0 = ctile * BC;
 
@@ -413,11 +482,16 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
   };
   int j_all = 0;
   if constexpr (PIPE) {
-    // full tiles in front of the first masked one: single segment, tiles tile0 .. ; tile t is full iff (t + 1) * BC <= nk
-    int n_full = p.nseg == 1 ? (int)(p.seg[0].nk / BC) - tile0 : 0;
-    n_full = n_full < total_tiles ? n_full : total_tiles;
-    for (; j_all < n_full; ++j_all) tile_iter(j_all, std::true_type{});
-    asm volatile("s_nop 15\n\ts_nop 15");     // asm MFMA results -> VALU / builtin readers behind the loop (hipcc does not see the hazard)
+    // Segment by segment (one segment on a single GPU; one per rank / source after a view-sharded exchange): the FULL tiles of the
+    // segment in a loop of the pinned body -- tile t of a segment is full iff (t + 1) * BC <= nk -- then its masked last tile, if
+    // any, through the compiler-scheduled body (a single call per segment, outside the hot loop).
+    while (j_all < total_tiles) {
+      int n_full = c_nk / BC - ctile;
+      n_full = n_full < total_tiles - j_all ? n_full : total_tiles - j_all;
+      for (int i = 0; i < n_full; ++i, ++j_all) tile_iter(j_all, std::true_type{});
+      asm volatile("s_nop 15\n\ts_nop 15");   // asm MFMA results -> VALU / builtin readers behind the loop (hipcc does not see the hazard)
+      if (j_all < total_tiles && (ctile + 1) * BC > c_nk) { tile_iter(j_all, std::false_type{}); ++j_all; }   // the current tile is a masked one (else: the segment ended on a full tile and the cursor is already in the next segment)
+    }
   }
   for (; j_all < total_tiles; ++j_all) tile_iter(j_all, std::false_type{});
   if constexpr (DMA) __syncthreads();              // drain the tail transfers before the ring is reused (fallback pass) or the workgroup ends
@@ -432,7 +506,7 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
 
 // Normalise and store a wave's QB x 16 rows: the caller's final layout (token-major or head-major, + optional log-sum-exp)
 // or, in a split-KV pass, the head-major partial [split][entry][nq_pad][64] with its log-sum-exp.
-template <typename T, int QB>
+template <typename T, int QB, bool X3 = false>
 OVG_DEV void write_out(const ovg_attn_params& p, const f32x4 (&o)[QB][4], const f32x4 (&lacc)[QB], const f32x4 (&negm)[QB],
                        const int bh, const int q0, const int sp, const int splits) {
   const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
@@ -452,11 +526,14 @@ OVG_DEV void write_out(const ovg_attn_params& p, const f32x4 (&o)[QB][4], const 
         if (g == 0) p.ws_lse[row] = __builtin_amdgcn_logf(lacc[qb][0]) - negm[qb][0];
         continue;
       }
-      T* dst = p.out_bh_stride > 0 ? static_cast<T*>(p.out) + (int64_t)bh * p.out_bh_stride + (int64_t)q * p.ldo + 4 * g
-                                   : static_cast<T*>(p.out) + ((int64_t)bq * nq + q) * p.ldo + hh * OVG_D + 4 * g;
+      const int64_t off = p.out_bh_stride > 0 ? (int64_t)bh * p.out_bh_stride + (int64_t)q * p.ldo + 4 * g
+                                              : ((int64_t)bq * nq + q) * p.ldo + hh * OVG_D + 4 * g;
+      T* dst = static_cast<T*>(p.out) + off;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        store4<T>(dst + 16 * dt, o[qb][dt][0] * inv, o[qb][dt][1] * inv, o[qb][dt][2] * inv, o[qb][dt][3] * inv);
+      for (int dt = 0; dt < 4; ++dt) {
+        if constexpr (X3) store4_hilo(dst + 16 * dt, static_cast<f16_t*>(p.out_lo) + off + 16 * dt, o[qb][dt][0] * inv, o[qb][dt][1] * inv, o[qb][dt][2] * inv, o[qb][dt][3] * inv);
+        else store4<T>(dst + 16 * dt, o[qb][dt][0] * inv, o[qb][dt][1] * inv, o[qb][dt][2] * inv, o[qb][dt][3] * inv);
+      }
       if (p.lse != nullptr && g == 0) p.lse[(int64_t)bh * p.nq_pad + q] = __builtin_amdgcn_logf(lacc[qb][0]) - negm[qb][0];
     }
   }
@@ -465,11 +542,11 @@ OVG_DEV void write_out(const ovg_attn_params& p, const f32x4 (&o)[QB][4], const 
 }  // namespace attn16
 
 // MODE: 0 = speculative anchored softmax + verified fallback, 1 = lazy-rescale only, 2 = forced fallback (tests)
-template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false, int DMA = 0>   // OCC: minimum waves per SIMD the register allocation must allow
+template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false, int DMA = 0, bool X3 = false>   // OCC: minimum waves per SIMD the register allocation must allow; X3: split-f16 planes (run_tiles)
 __global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params p, int nqt, int total_tiles, int splits, int per_split, int q_row0) {   // q tiles [0, nqt) of the rows starting at q_row0
   static_assert(sizeof(T) == 2, "16-bit types only");
   constexpr int RB = 128, KT_B = BC * RB, VT_B = OVG_D * RB, BQ = 16 * QB * WAVES;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[(DMA ? DMA : 2) * (KT_B + VT_B)];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(DMA ? DMA : 2) * (X3 ? 2 : 1) * (KT_B + VT_B)];
 
   const int tid = threadIdx.x, wave = tid >> 6;
   // logical id -> (batch entry, key split, q tile), q tile fastest: the workgroups that run side by side on an XCD share
@@ -483,8 +560,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params
 
   f32x4 o[QB][4], lacc[QB], negm[QB];
   if constexpr (MODE == 1) {
-    attn16::run_tiles<T, QB, WAVES, 0, VSUM, DMA>(p, lds, bh, q0, t0, nt, o, lacc, negm);
+    attn16::run_tiles<T, QB, WAVES, 0, VSUM, DMA, X3>(p, lds, bh, q0, t0, nt, o, lacc, negm);
   } else {
+    static_assert(!X3, "split-f16 runs the lazy-rescale body only");
     attn16::run_tiles<T, QB, WAVES, 2, VSUM, DMA>(p, lds, bh, q0, t0, nt, o, lacc, negm);
     bool bad = MODE == 2;
 #pragma unroll
@@ -502,7 +580,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params
     }
   }
 
-  attn16::write_out<T, QB>(p, o, lacc, negm, bh, q0, sp, splits);
+  attn16::write_out<T, QB, X3>(p, o, lacc, negm, bh, q0, sp, splits);
 }
 
 // Second launch of a split-KV call: out[entry, q, :] = sum_s w_s part[s][entry, q, :] / sum_s w_s, w_s = 2^(lse_s - max lse)

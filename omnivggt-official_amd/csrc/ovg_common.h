@@ -73,6 +73,27 @@ template <> OVG_DEV void store4<f16_t>(f16_t* dst, float a, float b, float c, fl
   *reinterpret_cast<f16x4*>(dst) = v;
 }
 
+// ---------------------------------------------------------------------------
+// Split-f16 mode (OVG_F16X2, "f32x"): x ~ hi + lo with hi = f16(x) (saturated at the largest finite f16) and lo = f16(x - hi),
+// stored in two f16 tensors of the same shape. |x - hi - lo| <= 2^-22 |x| while lo is a normal f16 (|x| >= 2^-3), <= 2^-25 absolute
+// below (lo subnormal; the f16 MFMA keeps subnormal inputs). Kernels take the mode as a `bool X3` template flag next to T = f16_t:
+// every contraction runs three MFMAs (lo*hi, hi*lo, hi*hi -- small terms first) into the same f32 accumulator.
+// ---------------------------------------------------------------------------
+OVG_DEV float f16_sat(float x) { return __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }
+OVG_DEV void store4_hilo(f16_t* hi, f16_t* lo, float a, float b, float c, float d) {
+  typedef __attribute__((__vector_size__(4 * sizeof(_Float16)))) _Float16 f16x4;
+  const f16x4 h = {static_cast<f16_t>(f16_sat(a)), static_cast<f16_t>(f16_sat(b)), static_cast<f16_t>(f16_sat(c)), static_cast<f16_t>(f16_sat(d))};
+  const f16x4 l = {static_cast<f16_t>(f16_sat(a - static_cast<float>(h[0]))), static_cast<f16_t>(f16_sat(b - static_cast<float>(h[1]))),
+                   static_cast<f16_t>(f16_sat(c - static_cast<float>(h[2]))), static_cast<f16_t>(f16_sat(d - static_cast<float>(h[3])))};
+  *reinterpret_cast<f16x4*>(hi) = h;
+  *reinterpret_cast<f16x4*>(lo) = l;
+}
+// one value -> (hi, lo)
+OVG_DEV void split_hilo(float x, f16_t& hi, f16_t& lo) {
+  hi = static_cast<f16_t>(f16_sat(x));
+  lo = static_cast<f16_t>(f16_sat(x - static_cast<float>(hi)));
+}
+
 // LDS tile of rows of RB bytes (RB = 128 or 256), 16-byte chunks XOR-swizzled so
 // that ds_read_b128 of {16 rows x one chunk column} is bank-conflict free:
 //   128 B rows: chunk ^= (row>>1)&7   (two rows share one 256 B bank row)

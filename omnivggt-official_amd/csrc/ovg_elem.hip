@@ -21,7 +21,7 @@ OVG_DEV void row_stats(const f32x4 (&v)[4], float& mean, float& rstd, float eps)
   rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / 1024.0f) + eps);
 }
 
-template <typename T, bool OUT_F32>
+template <typename T, bool OUT_F32, bool X3 = false>   // X3 (OVG_F16X2): T = f16_t, the row goes out as two f16 planes y (hi) / y_lo
 __global__ __launch_bounds__(256) void layernorm_kernel(ovg_layernorm_params p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const f32x4* wv = reinterpret_cast<const f32x4*>(p.weight);
@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(ovg_layernorm_params p) 
       const f32x4 y = (v[i] - mean) * rstd * w[i] + b[i];
       const int col = 4 * (lane + 64 * i);
       if constexpr (OUT_F32) *reinterpret_cast<f32x4*>(static_cast<float*>(p.y) + row * p.ldy + col) = y;
+      else if constexpr (X3) store4_hilo(static_cast<f16_t*>(p.y) + row * p.ldy + col, static_cast<f16_t*>(p.y_lo) + row * p.ldy + col, y[0], y[1], y[2], y[3]);
       else store4<T>(static_cast<T*>(p.y) + row * p.ldy + col, y[0], y[1], y[2], y[3]);
     }
   }
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(ovg_layernorm_params p) 
 // im2col for the k=14,s=14 patch convolutions.  One thread = 8 consecutive k of
 // one patch row (16 B of bf16/f16 output, 32 B of f32).
 // --------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool X3 = false>
 __global__ __launch_bounds__(256) void im2col_kernel(ovg_im2col_params p, int gh, int gw, int64_t total) {
   const int kc = (int)(p.k_pad / 8);
   const int kvalid = p.C * 196;
@@ -89,8 +90,14 @@ __global__ __launch_bounds__(256) void im2col_kernel(ovg_im2col_params p, int gh
       o[e] = val;
     }
     T* dst = static_cast<T*>(p.out) + prow * p.k_pad + c8 * 8;
-    store4<T>(dst, o[0], o[1], o[2], o[3]);
-    store4<T>(dst + 4, o[4], o[5], o[6], o[7]);
+    if constexpr (X3) {
+      f16_t* dlo = static_cast<f16_t*>(p.out_lo) + prow * p.k_pad + c8 * 8;
+      store4_hilo(dst, dlo, o[0], o[1], o[2], o[3]);
+      store4_hilo(dst + 4, dlo + 4, o[4], o[5], o[6], o[7]);
+    } else {
+      store4<T>(dst, o[0], o[1], o[2], o[3]);
+      store4<T>(dst + 4, o[4], o[5], o[6], o[7]);
+    }
   }
 }
 
@@ -266,7 +273,7 @@ extern "C" int ovg_attn_merge(const ovg_attn_merge_params* p, void* stream) {
 }
 
 // f32 [rows, k] -> dtype [rows, k_pad], zero beyond k (header: ovg_pack_weights); one thread = 8 output elements
-template <typename T>
+template <typename T, bool X3 = false>
 __global__ __launch_bounds__(256) void pack_weights_kernel(ovg_pack_weights_params p, int64_t total, int cpr) {
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     const int64_t row = idx / cpr;
@@ -276,8 +283,14 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(ovg_pack_weights_para
     float v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (c0 + i) < p.k ? src[c0 + i] : 0.f;
-    store4<T>(dst, v[0], v[1], v[2], v[3]);
-    store4<T>(dst + 4, v[4], v[5], v[6], v[7]);
+    if constexpr (X3) {
+      f16_t* dlo = static_cast<f16_t*>(p.dst_lo) + row * p.ldd + c0;
+      store4_hilo(dst, dlo, v[0], v[1], v[2], v[3]);
+      store4_hilo(dst + 4, dlo + 4, v[4], v[5], v[6], v[7]);
+    } else {
+      store4<T>(dst, v[0], v[1], v[2], v[3]);
+      store4<T>(dst + 4, v[4], v[5], v[6], v[7]);
+    }
   }
 }
 
@@ -292,6 +305,9 @@ extern "C" int ovg_pack_weights(const ovg_pack_weights_params* p, void* stream) 
     case OVG_BF16: OVG_LAUNCH((pack_weights_kernel<bf16_t>), grid, block, 0, st, *p, total, cpr); break;
     case OVG_F16: OVG_LAUNCH((pack_weights_kernel<f16_t>), grid, block, 0, st, *p, total, cpr); break;
     case OVG_F32: OVG_LAUNCH((pack_weights_kernel<float>), grid, block, 0, st, *p, total, cpr); break;
+    case OVG_F16X2:
+      if (!p->dst_lo || !al16(p->dst_lo)) return OVG_E_ARG;
+      OVG_LAUNCH((pack_weights_kernel<f16_t, true>), grid, block, 0, st, *p, total, cpr); break;
     default: return OVG_E_DTYPE;
   }
   OVG_CHECK_LAUNCH();
@@ -308,6 +324,9 @@ extern "C" int ovg_layernorm(const ovg_layernorm_params* p, void* stream) {
     case OVG_BF16: OVG_LAUNCH((layernorm_kernel<bf16_t, false>), grid, block, 0, st, *p); break;
     case OVG_F16: OVG_LAUNCH((layernorm_kernel<f16_t, false>), grid, block, 0, st, *p); break;
     case OVG_F32: OVG_LAUNCH((layernorm_kernel<float, true>), grid, block, 0, st, *p); break;
+    case OVG_F16X2:
+      if (!p->y_lo || !al16(p->y_lo)) return OVG_E_ARG;
+      OVG_LAUNCH((layernorm_kernel<f16_t, false, true>), grid, block, 0, st, *p); break;
     default: return OVG_E_DTYPE;
   }
   OVG_CHECK_LAUNCH();
@@ -327,6 +346,9 @@ extern "C" int ovg_im2col(const ovg_im2col_params* p, void* stream) {
     case OVG_BF16: OVG_LAUNCH((im2col_kernel<bf16_t>), grid, block, 0, st, *p, gh, gw, total); break;
     case OVG_F16: OVG_LAUNCH((im2col_kernel<f16_t>), grid, block, 0, st, *p, gh, gw, total); break;
     case OVG_F32: OVG_LAUNCH((im2col_kernel<float>), grid, block, 0, st, *p, gh, gw, total); break;
+    case OVG_F16X2:
+      if (!p->out_lo || !al16(p->out_lo)) return OVG_E_ARG;
+      OVG_LAUNCH((im2col_kernel<f16_t, true>), grid, block, 0, st, *p, gh, gw, total); break;
     default: return OVG_E_DTYPE;
   }
   OVG_CHECK_LAUNCH();

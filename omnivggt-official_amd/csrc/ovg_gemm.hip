@@ -89,9 +89,13 @@ OVG_DEV void tile_coords(int lid, int mtiles, int ntiles_gm, int& tm, int& tn) {
 // ---------------------------------------------------------------------------
 // Main loop: leaves acc[nt][mt] = C[n = n0w + 16nt + 4g + r][m = m0w + 16mt + (lane&15)]
 // ---------------------------------------------------------------------------
-template <typename T, bool SWAP = false>   // SWAP: operands trade places, every 16 x 16 block transposed (see ovg_gemm256.h)
+// X3 (OVG_F16X2): the operands are (hi, lo) plane pairs; the k loop runs three passes over K into the same accumulators --
+// x_lo * w_hi, x_hi * w_lo, x_hi * w_hi (small terms first) -- as ONE loop of 3 nk virtual k-stages whose source planes are picked
+// per stage (wave-uniform selects), so the staging pipeline never drains between the passes.
+template <typename T, bool SWAP = false, bool X3 = false>   // SWAP: operands trade places, every 16 x 16 block transposed (see ovg_gemm256.h)
 OVG_DEV void gemm_mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict__ W, int64_t ldw,
-                           int M, int N, int K, int m0, int n0, unsigned char* lds, f32x4 (&acc)[4][4]) {
+                           int M, int N, int K, int m0, int n0, unsigned char* lds, f32x4 (&acc)[4][4],
+                           const T* __restrict__ Xlo = nullptr, const T* __restrict__ Wlo = nullptr) {
   constexpr int BKB = 128;                       // bytes of k per step
   unsigned char* Ws = lds;
   unsigned char* Xs = lds + BN * BKB;
@@ -116,12 +120,29 @@ OVG_DEV void gemm_mainloop(const T* __restrict__ X, int64_t ldx, const T* __rest
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (K * (int)sizeof(T)) / BKB;
+  const int nk1 = (K * (int)sizeof(T)) / BKB;
+  const int nk = X3 ? 3 * nk1 : nk1;
+  const int64_t dxl = X3 ? reinterpret_cast<const unsigned char*>(Xlo) - reinterpret_cast<const unsigned char*>(X) : 0;
+  const int64_t dwl = X3 ? reinterpret_cast<const unsigned char*>(Wlo) - reinterpret_cast<const unsigned char*>(W) : 0;
+  auto src_off = [&](int kt, int64_t& xo, int64_t& wo) {     // byte offsets of virtual k-stage kt from the hi-plane row pointers
+    if constexpr (X3) {
+      const int pass = kt >= 2 * nk1 ? 2 : (kt >= nk1 ? 1 : 0);
+      const int64_t kb = (int64_t)(kt - pass * nk1) * BKB;
+      xo = kb + (pass == 0 ? dxl : 0);
+      wo = kb + (pass == 1 ? dwl : 0);
+    } else {
+      xo = wo = (int64_t)kt * BKB;
+    }
+  };
   u32x4 rx[4], rw[4];
+  {
+    int64_t xo, wo;
+    src_off(0, xo, wo);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    rx[i] = *reinterpret_cast<const u32x4*>(xg[i]);
-    rw[i] = *reinterpret_cast<const u32x4*>(wg[i]);
+    for (int i = 0; i < 4; ++i) {
+      rx[i] = *reinterpret_cast<const u32x4*>(xg[i] + xo);
+      rw[i] = *reinterpret_cast<const u32x4*>(wg[i] + wo);
+    }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -136,10 +157,12 @@ OVG_DEV void gemm_mainloop(const T* __restrict__ X, int64_t ldx, const T* __rest
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = (kt + 1) < nk;
     if (more) {
+      int64_t xo, wo;
+      src_off(kt + 1, xo, wo);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        rx[i] = *reinterpret_cast<const u32x4*>(xg[i] + (int64_t)(kt + 1) * BKB);
-        rw[i] = *reinterpret_cast<const u32x4*>(wg[i] + (int64_t)(kt + 1) * BKB);
+        rx[i] = *reinterpret_cast<const u32x4*>(xg[i] + xo);
+        rw[i] = *reinterpret_cast<const u32x4*>(wg[i] + wo);
       }
     }
 #pragma unroll
@@ -182,7 +205,7 @@ OVG_DEV void gemm_mainloop(const T* __restrict__ X, int64_t ldx, const T* __rest
 // Now: the per-column vectors (bias, gamma) are loaded ONCE per wave, the row loop bodies are branch-free (row
 // indices clamped for the loads, only the store is predicated), so the four residual / table loads of a row block
 // -- and, registers permitting, the next row block's -- are in flight together.
-template <typename T, int EPI, bool OUT_F32, int MT, bool INJECT, int XP = 0>   // XP = 1 (OVG_TILE_R02_EPILOGUE, A/B flag): the r02 erf_as GELU instead of the polynomial one
+template <typename T, int EPI, bool OUT_F32, int MT, bool INJECT, int XP = 0, bool X3 = false>   // XP = 1 (OVG_TILE_R02_EPILOGUE, A/B flag): the r02 erf_as GELU instead of the polynomial one; X3: split-f16 outputs (hi / lo planes), libm erff
 OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int n_w0) {
   const int M = (int)p.M, N = (int)p.N;
   const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
@@ -259,8 +282,9 @@ OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)
     for (int nt = 0; nt < 4; ++nt) {
       v[nt] = acc[nt][mt] + bias[nt];
       if constexpr (EPI == OVG_EPI_GELU) {
-        if constexpr (XP || sizeof(T) == 4) {        // f32 parity mode: libm erff; XP (A/B flag OVG_TILE_R02_EPILOGUE): the r02 erf_as form; else the polynomial form below
-          v[nt][0] = gelu_erf<T>(v[nt][0]); v[nt][1] = gelu_erf<T>(v[nt][1]); v[nt][2] = gelu_erf<T>(v[nt][2]); v[nt][3] = gelu_erf<T>(v[nt][3]);
+        if constexpr (XP || sizeof(T) == 4 || X3) {  // f32 / split-f16 parity modes: libm erff; XP (A/B flag OVG_TILE_R02_EPILOGUE): the r02 erf_as form; else the polynomial form below
+          using GT = typename std::conditional<X3, float, T>::type;
+          v[nt][0] = gelu_erf<GT>(v[nt][0]); v[nt][1] = gelu_erf<GT>(v[nt][1]); v[nt][2] = gelu_erf<GT>(v[nt][2]); v[nt][3] = gelu_erf<GT>(v[nt][3]);
         }
         if constexpr (std::is_same<T, f16_t>::value && XP) {
           // f16 range guard: the hidden activation is the one 16-bit tensor fed by an unnormalised f32 sum (DINOv2-style
@@ -274,7 +298,7 @@ OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)
       if constexpr (EPI == OVG_EPI_RES && INJECT) v[nt] += on[cs] * inj[cs][nt];
       if constexpr (EPI == OVG_EPI_PATCH) v[nt] += ex[cs][nt];
     }
-    if constexpr (EPI == OVG_EPI_GELU && !XP && sizeof(T) == 2) {
+    if constexpr (EPI == OVG_EPI_GELU && !XP && !X3 && sizeof(T) == 2) {
       gelu_poly16(v);
       if constexpr (std::is_same<T, f16_t>::value) {
 #pragma unroll
@@ -289,6 +313,9 @@ OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)
       for (int nt = 0; nt < 4; ++nt) {
         if constexpr (OUT_F32 || EPI == OVG_EPI_RES || EPI == OVG_EPI_PATCH) {
           *reinterpret_cast<f32x4*>(static_cast<float*>(p.y) + orow * p.ldy + ncol + nt * 16) = v[nt];
+        } else if constexpr (X3) {
+          const int64_t off = orow * p.ldy + ncol + nt * 16;
+          store4_hilo(static_cast<f16_t*>(p.y) + off, static_cast<f16_t*>(p.y_lo) + off, v[nt][0], v[nt][1], v[nt][2], v[nt][3]);
         } else {
           store4<T>(static_cast<T*>(p.y) + orow * p.ldy + ncol + nt * 16, v[nt][0], v[nt][1], v[nt][2], v[nt][3]);
         }
@@ -409,20 +436,20 @@ OVG_DEV void linear_epilogue_staged(const ovg_linear_params& p, const f32x4 (&ac
   }
 }
 
-template <typename T, int EPI, bool OUT_F32, int MT, int XP = 0>
+template <typename T, int EPI, bool OUT_F32, int MT, int XP = 0, bool X3 = false>
 OVG_DEV void linear_epilogue(const ovg_linear_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int n_w0) {
   if constexpr (EPI == OVG_EPI_RES) {
-    if (p.inject != nullptr) { linear_epilogue_impl<T, EPI, OUT_F32, MT, true, XP>(p, acc, m_w0, n_w0); return; }
+    if (p.inject != nullptr) { linear_epilogue_impl<T, EPI, OUT_F32, MT, true, XP, X3>(p, acc, m_w0, n_w0); return; }
   }
-  linear_epilogue_impl<T, EPI, OUT_F32, MT, false, XP>(p, acc, m_w0, n_w0);
+  linear_epilogue_impl<T, EPI, OUT_F32, MT, false, XP, X3>(p, acc, m_w0, n_w0);
 }
 
 // Which epilogue a wave of a 16-bit kernel takes (wave-uniform): the staged one unless the caller pinned the r02 register form (XP), the output
 // cannot take 16-byte stores, or -- residual form -- one of the wave's rows is a camera-injection row (m % inj_period == 0: 1 row in 1374).
-template <typename T, int EPI, bool OUT_F32, int MT, int XP>
+template <typename T, int EPI, bool OUT_F32, int MT, int XP, bool X3 = false>
 OVG_DEV void linear_epilogue_auto(const ovg_linear_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int n_w0, unsigned char* img) {
   if constexpr (!XP && sizeof(T) == 2) {
-    if constexpr ((EPI == OVG_EPI_STORE || EPI == OVG_EPI_GELU) && !OUT_F32) {
+    if constexpr ((EPI == OVG_EPI_STORE || EPI == OVG_EPI_GELU) && !OUT_F32 && !X3) {   // split-f16 outputs (two planes) keep the register form
       if (((p.ldy * (int64_t)sizeof(T)) & 15) == 0) { linear_epilogue_staged<T, EPI, MT>(p, acc, m_w0, n_w0, img); return; }
     }
     if constexpr (EPI == OVG_EPI_RES) {
@@ -434,11 +461,11 @@ OVG_DEV void linear_epilogue_auto(const ovg_linear_params& p, const f32x4 (&acc)
       if (!inj_here) { linear_epilogue_staged<T, EPI, MT>(p, acc, m_w0, n_w0, img); return; }
     }
   }
-  linear_epilogue<T, EPI, OUT_F32, MT, XP>(p, acc, m_w0, n_w0);
+  linear_epilogue<T, EPI, OUT_F32, MT, XP, X3>(p, acc, m_w0, n_w0);
 }
 
 
-template <typename T, int EPI, bool OUT_F32, int XP = 0>
+template <typename T, int EPI, bool OUT_F32, int XP = 0, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void linear_kernel(ovg_linear_params p, int ntiles_n) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128];
   const int M = (int)p.M, N = (int)p.N, K = (int)p.K;
@@ -446,10 +473,11 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(ovg_linear_params p, int
   tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + BM - 1) / BM, ntiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   f32x4 acc[4][4];
-  gemm_mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds, acc);
+  gemm_mainloop<T, false, X3>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds, acc,
+                              static_cast<const T*>(p.x_lo), static_cast<const T*>(p.w_lo));
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // gemm_mainloop ends behind a __syncthreads: both stage buffers (32 KB) are idle, wave w owns 8 KB of them
-  linear_epilogue_auto<T, EPI, OUT_F32, 4, XP>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64, lds + wave * 8192);
+  linear_epilogue_auto<T, EPI, OUT_F32, 4, XP, X3>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64, lds + wave * 8192);
 }
 
 // ---------------------------------------------------------------------------
@@ -461,11 +489,11 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(ovg_linear_params p, int
 // branch-free up to the predicated store. The RoPE cos / sin table (<= 128 positions x 16 frequencies, 16 KB) is
 // copied into LDS when the kernel starts and read from there (first version: four dependent global loads per row
 // block, one exposed L2 round trip each time, ~10 us per 256 x 256 tile).
-template <typename T, int MT, bool NORM, bool ROPE>
-OVG_DEV void qk_rows(const f32x4 (&acc)[4][MT], const float (&bias)[16], const float* __restrict__ nw_p, const float* __restrict__ nb_p,
+template <typename T, int MT, bool NORM, bool ROPE, bool X3 = false>
+OVG_DEV void qk_rows(const f32x4 (&acc)[4][MT], const float* __restrict__ nw_p, const float* __restrict__ nb_p,
                      const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, T* __restrict__ out, const int64_t npad,
                      const int m_w0, const int M, const int seq, const int h, const int tokens_per_view, const int n_special,
-                     const int grid_w, const float qk_eps, const float scale, unsigned char* img = nullptr) {
+                     const int grid_w, const float qk_eps, const float scale, unsigned char* img = nullptr, T* __restrict__ out_lo = nullptr) {
   // img != nullptr (16-bit modes): the wave's 2 KB x MT of idle LDS -- the 64-wide head rows (128 B = one line per token) are written into
   // a row-major image and stored as whole lines afterwards (see linear_epilogue_staged)
   const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
@@ -504,7 +532,7 @@ OVG_DEV void qk_rows(const f32x4 (&acc)[4][MT], const float (&bias)[16], const f
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[nt][mt][r] + bias[nt * 4 + r];
+      for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[nt][mt][r];      // bias already added (qk_epilogue)
     if constexpr (NORM) {
       float s = 0.f;
 #pragma unroll
@@ -516,7 +544,7 @@ OVG_DEV void qk_rows(const f32x4 (&acc)[4][MT], const float (&bias)[16], const f
       for (int i = 0; i < 16; ++i) { const float d = v[i] - mean; q += d * d; }
       q = quad16_sum(q);
       float rstd;
-      if constexpr (sizeof(T) == 4) rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + qk_eps);     // parity mode: IEEE sqrt + divide
+      if constexpr (sizeof(T) == 4 || X3) rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + qk_eps);     // parity modes: IEEE sqrt + divide
       else rstd = __builtin_amdgcn_rsqf(q * (1.0f / 64.0f) + qk_eps);                     // 1 ulp, far below bf16 / f16 resolution
 #pragma unroll
       for (int i = 0; i < 16; ++i) v[i] = (v[i] - mean) * rstd * nw[i] + nb[i];
@@ -542,9 +570,13 @@ OVG_DEV void qk_rows(const f32x4 (&acc)[4][MT], const float (&bias)[16], const f
       }
     }
     if (valid) {
-      T* dst = out + (((int64_t)bidx * OVG_H + h) * npad + n) * OVG_D + 4 * g;
+      const int64_t off = (((int64_t)bidx * OVG_H + h) * npad + n) * OVG_D + 4 * g;
+      T* dst = out + off;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) store4<T>(dst + nt * 16, v[nt * 4], v[nt * 4 + 1], v[nt * 4 + 2], v[nt * 4 + 3]);
+      for (int nt = 0; nt < 4; ++nt) {
+        if constexpr (X3) store4_hilo(dst + nt * 16, out_lo + off + nt * 16, v[nt * 4], v[nt * 4 + 1], v[nt * 4 + 2], v[nt * 4 + 3]);
+        else store4<T>(dst + nt * 16, v[nt * 4], v[nt * 4 + 1], v[nt * 4 + 2], v[nt * 4 + 3]);
+      }
     }
   }
   if constexpr (sizeof(T) == 2) {
@@ -567,8 +599,8 @@ OVG_DEV void qk_rows(const f32x4 (&acc)[4][MT], const float (&bias)[16], const f
   }
 }
 
-template <typename T, int MT>
-OVG_DEV void qk_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int ncol0_,
+template <typename T, int MT, bool X3 = false>
+OVG_DEV void qk_epilogue(const ovg_qkv_params& p, f32x4 (&acc)[4][MT], const int m_w0, const int ncol0_,
                          const float* rope_c, const float* rope_s, unsigned char* img = nullptr) {
   const int ncol0 = __builtin_amdgcn_readfirstlane(ncol0_);   // wave-uniform: keep the q/k/v dispatch scalar
   const int M = (int)p.M;
@@ -577,21 +609,24 @@ OVG_DEV void qk_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], con
   const int which = ncol0 / OVG_C;                      // 0 q, 1 k (uniform per wave; V^T tiles go through v_epilogue)
   const int h = (ncol0 % OVG_C) / OVG_D;                // head of this wave's 64 columns
 
-  float bias[16];
+  // the bias goes into the accumulators once, up front: 16 registers fewer live across the row loop (r04: the 128 x 128 kernel sits at its
+  // 168-VGPR cap -- __launch_bounds__(256, 3) -- and spilled 17 registers into scratch inside this epilogue)
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + ncol0 + nt * 16 + 4 * g);
-    bias[nt * 4 + 0] = b[0]; bias[nt * 4 + 1] = b[1]; bias[nt * 4 + 2] = b[2]; bias[nt * 4 + 3] = b[3];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[nt][mt] += b;
   }
   {
     const float* nw_p = which == 0 ? p.qn_w : p.kn_w;
     const float* nb_p = which == 0 ? p.qn_b : p.kn_b;
     T* out = static_cast<T*>(which == 0 ? p.q : p.k);
+    T* out_lo = static_cast<T*>(which == 0 ? p.q_lo : p.k_lo);
     const int64_t npad = which == 0 ? p.nq_pad : p.nk_pad;
     const float scale = which == 0 ? p.q_scale : 1.0f;
     const int tpv = (int)p.tokens_per_view;
-#define OVG_QK_ROWS(NORM, ROPE) qk_rows<T, MT, NORM, ROPE>(acc, bias, nw_p, nb_p, rope_c, rope_s, out, npad, m_w0, M, seq, h, \
-                                                             tpv, p.n_special, p.grid_w, p.qk_eps, scale, img)
+#define OVG_QK_ROWS(NORM, ROPE) qk_rows<T, MT, NORM, ROPE, X3>(acc, nw_p, nb_p, rope_c, rope_s, out, npad, m_w0, M, seq, h, \
+                                                                 tpv, p.n_special, p.grid_w, p.qk_eps, scale, img, out_lo)
     if (p.qk_norm) { if (p.rope) OVG_QK_ROWS(true, true); else OVG_QK_ROWS(true, false); }
     else { if (p.rope) OVG_QK_ROWS(false, true); else OVG_QK_ROWS(false, false); }
 #undef OVG_QK_ROWS
@@ -601,7 +636,7 @@ OVG_DEV void qk_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], con
 // V^T tiles: the main loop ran with SWAP, so acc[nt][mt][r] = V[token m = m_w0 + 16 mt + 4g + r][feature d = 16 nt + (lane & 15)]:
 // four consecutive tokens of one feature per register group = ONE 8-byte store into V^T [B*H, 64, nk_pad] (the first
 // version held 4 features of one token and issued 16 two-byte stores per row block, each block fenced by a vmcnt(0)).
-template <typename T, int MT>
+template <typename T, int MT, bool X3 = false>
 OVG_DEV void v_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int ncol0_) {
   const int ncol0 = __builtin_amdgcn_readfirstlane(ncol0_);
   const int M = (int)p.M, seq = (int)p.seq;
@@ -612,6 +647,7 @@ OVG_DEV void v_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], cons
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) bias[nt] = p.bias[ncol0 + nt * 16 + lr];
   T* vt = static_cast<T*>(p.vt);
+  const int64_t dlo = X3 ? static_cast<T*>(p.vt_lo) - vt : 0;      // element offset of the lo plane (split-f16)
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = m_w0 + mt * 16 + 4 * g;               // first of this lane's 4 tokens
@@ -631,9 +667,21 @@ OVG_DEV void v_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], cons
       const f32x4 v = acc[nt][mt] + bias[nt];
       T* dst = rowb + (int64_t)nt * 16 * p.nk_pad;
       if (whole) {
-        store4<T>(dst + c0, v[0], v[1], v[2], v[3]);
+        if constexpr (X3) store4_hilo(dst + c0, dst + dlo + c0, v[0], v[1], v[2], v[3]);
+        else store4<T>(dst + c0, v[0], v[1], v[2], v[3]);
       } else if (halves) {
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (X3) {
+          f16_t ph[4], pl[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) split_hilo(v[r], ph[r], pl[r]);
+          uint32_t w0, w1, l0, l1;
+          __builtin_memcpy(&w0, ph, 4); __builtin_memcpy(&w1, ph + 2, 4);
+          __builtin_memcpy(&l0, pl, 4); __builtin_memcpy(&l1, pl + 2, 4);
+          *reinterpret_cast<uint32_t*>(dst + c0) = w0;
+          *reinterpret_cast<uint32_t*>(dst + c2) = w1;
+          *reinterpret_cast<uint32_t*>(dst + dlo + c0) = l0;
+          *reinterpret_cast<uint32_t*>(dst + dlo + c2) = l1;
+        } else if constexpr (sizeof(T) == 2) {
           T pr[4] = {TT<T>::from_f32(v[0]), TT<T>::from_f32(v[1]), TT<T>::from_f32(v[2]), TT<T>::from_f32(v[3])};
           uint32_t w0, w1;
           __builtin_memcpy(&w0, pr, 4);
@@ -648,7 +696,9 @@ OVG_DEV void v_epilogue(const ovg_qkv_params& p, const f32x4 (&acc)[4][MT], cons
           if (mr < M) {
             int br, nr;
             div_seq.divmod(mr, br, nr);
-            vt[(((int64_t)br * OVG_H + h) * OVG_D + nt * 16 + lr) * p.nk_pad + (sizeof(T) == 2 ? vt_pos16(nr) : nr)] = TT<T>::from_f32(v[r]);
+            const int64_t at = (((int64_t)br * OVG_H + h) * OVG_D + nt * 16 + lr) * p.nk_pad + (sizeof(T) == 2 ? vt_pos16(nr) : nr);
+            if constexpr (X3) { f16_t eh, el; split_hilo(v[r], eh, el); vt[at] = eh; vt[at + dlo] = el; }
+            else vt[at] = TT<T>::from_f32(v[r]);
           }
         }
       }
@@ -676,7 +726,7 @@ OVG_DEV void stage_rope_table(const ovg_qkv_params& p, unsigned char* tab, int n
 }
 constexpr int ROPE_LDS_BYTES = 2 * 128 * 16 * 4;          // max_pos <= 128 (ovg_qkv checks)
 
-template <typename T>
+template <typename T, bool X3 = false>
 __global__ __launch_bounds__(256, 3) void qkv_kernel(ovg_qkv_params p, int nt_begin, int nt_count) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128];
   constexpr int N = 3 * OVG_C, K = OVG_C;
@@ -687,23 +737,25 @@ __global__ __launch_bounds__(256, 3) void qkv_kernel(ovg_qkv_params p, int nt_be
   const int wave = threadIdx.x >> 6;
   f32x4 acc[4][4];
   if (n0 >= 2 * OVG_C) {                                   // V^T tile (workgroup-uniform): transposed accumulators
-    gemm_mainloop<T, true>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
-    v_epilogue<T, 4>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64);
+    gemm_mainloop<T, true, X3>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc,
+                               static_cast<const T*>(p.x_lo), static_cast<const T*>(p.w_lo));
+    v_epilogue<T, 4, X3>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64);
   } else {
     // 3 workgroups per CU hide the RoPE-table round trips here: the table is read from global memory (L1 / L2 hits); staging it
     // in LDS cost more than it saved on these small tiles (the DMA sits in front of the register-staged loop's first loads)
-    gemm_mainloop<T, false>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc);
+    gemm_mainloop<T, false, X3>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds, acc,
+                                static_cast<const T*>(p.x_lo), static_cast<const T*>(p.w_lo));
     // behind the main loop's last __syncthreads the two stage buffers are idle: wave w stages its head rows through 8 KB of them
-    // (the OVG_TILE_R02_EPILOGUE flag keeps the r02 per-lane 8-byte stores: A/B)
-    unsigned char* img = (sizeof(T) == 2 && !(p.tile & OVG_TILE_R02_EPILOGUE)) ? lds + __builtin_amdgcn_readfirstlane(wave) * 8192 : nullptr;
-    qk_epilogue<T, 4>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64, p.rope_cos, p.rope_sin, img);
+    // (the OVG_TILE_R02_EPILOGUE flag keeps the r02 per-lane 8-byte stores: A/B; the split-f16 mode writes two planes from registers)
+    unsigned char* img = (sizeof(T) == 2 && !X3 && !(p.tile & OVG_TILE_R02_EPILOGUE)) ? lds + __builtin_amdgcn_readfirstlane(wave) * 8192 : nullptr;
+    qk_epilogue<T, 4, X3>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64, p.rope_cos, p.rope_sin, img);
   }
 }
 
 #include "ovg_gemm256.h"
 
 // 256 x 256 ping-pong variants (16-bit modes): same epilogues on acc[4][8]
-template <typename T, int EPI, bool OUT_F32, int XP = 0>
+template <typename T, int EPI, bool OUT_F32, int XP = 0, bool X3 = false>
 __global__ __launch_bounds__(512) void linear256_kernel(ovg_linear_params p, int ntiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds256[];
   const int M = (int)p.M, N = (int)p.N, K = (int)p.K;
@@ -711,13 +763,14 @@ __global__ __launch_bounds__(512) void linear256_kernel(ovg_linear_params p, int
   tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + g256::BM2 - 1) / g256::BM2, ntiles_n, tm, tn);
   const int m0 = tm * g256::BM2, n0 = tn * g256::BN2;
   f32x4 acc[4][8];
-  g256::mainloop<T>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds256, acc);
+  g256::mainloop<T, false, X3>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds256, acc,
+                               static_cast<const T*>(p.x_lo), static_cast<const T*>(p.w_lo));
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // the ring is idle: mainloop() returns behind its last barrier, every DMA waited for; wave w owns 16 KB of it
-  linear_epilogue_auto<T, EPI, OUT_F32, 8, XP>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, lds256 + wave * 16384);
+  linear_epilogue_auto<T, EPI, OUT_F32, 8, XP, X3>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, lds256 + wave * 16384);
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 __global__ __launch_bounds__(512) void qkv256_kernel(ovg_qkv_params p, int nt_begin, int nt_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds256[];   // ring (g256::LDS_BYTES) + RoPE table (ROPE_LDS_BYTES)
   constexpr int N = 3 * OVG_C, K = OVG_C;
@@ -728,15 +781,17 @@ __global__ __launch_bounds__(512) void qkv256_kernel(ovg_qkv_params p, int nt_be
   const int wave = threadIdx.x >> 6;
   f32x4 acc[4][8];
   if (n0 >= 2 * OVG_C) {                                   // V^T tile (workgroup-uniform): transposed accumulators
-    g256::mainloop<T, true>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds256, acc);
-    v_epilogue<T, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64);
+    g256::mainloop<T, true, X3>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds256, acc,
+                                static_cast<const T*>(p.x_lo), static_cast<const T*>(p.w_lo));
+    v_epilogue<T, 8, X3>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64);
   } else {
     float* rope_tab = reinterpret_cast<float*>(lds256 + g256::LDS_BYTES);
     stage_rope_table(p, lds256 + g256::LDS_BYTES, 8);      // older than every stage DMA: retired by the loop's first counted wait, visible after its barriers
-    g256::mainloop<T, false>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds256, acc);
+    g256::mainloop<T, false, X3>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds256, acc,
+                                 static_cast<const T*>(p.x_lo), static_cast<const T*>(p.w_lo));
     // the OVG_TILE_R02_EPILOGUE flag keeps the r02 per-lane 8-byte stores (A/B); otherwise whole head rows through the idle ring
-    unsigned char* img = (p.tile & OVG_TILE_R02_EPILOGUE) ? nullptr : lds256 + __builtin_amdgcn_readfirstlane(wave) * 16384;
-    qk_epilogue<T, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, rope_tab, rope_tab + 128 * 16, img);
+    unsigned char* img = (X3 || (p.tile & OVG_TILE_R02_EPILOGUE)) ? nullptr : lds256 + __builtin_amdgcn_readfirstlane(wave) * 16384;
+    qk_epilogue<T, 8, X3>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, rope_tab, rope_tab + 128 * 16, img);
   }
 }
 
@@ -847,6 +902,34 @@ int launch_linear(const ovg_linear_params& p, hipStream_t st) {
   return launch_linear128<T>(p, st);
 }
 
+// split-f16 mode (OVG_F16X2): the same kernels with X3 = true on f16 planes; 256 x 256 tiles from M >= 20 000 rows on (three times the
+// main loop per epilogue: the ping-pong loop's advantage grows), register-form epilogues for the two-plane 16-bit outputs
+template <int EPI, bool OUT_F32>
+int launch_linear_x3_one(const ovg_linear_params& p, hipStream_t st, bool big) {
+  if (big) {
+    const int ok = allow_big_lds(linear256_kernel<f16_t, EPI, OUT_F32, 0, true>);
+    if (ok != OVG_OK) return ok;
+    const int mt = (int)((p.M + g256::BM2 - 1) / g256::BM2), nt = (int)(p.N / g256::BN2);
+    OVG_LAUNCH((linear256_kernel<f16_t, EPI, OUT_F32, 0, true>), dim3(mt * nt), dim3(512), g256::LDS_BYTES, st, p, nt | (TILE_GROUP256 << 16));
+  } else {
+    const int mt = (int)((p.M + BM - 1) / BM), nt = (int)(p.N / BN);
+    OVG_LAUNCH((linear_kernel<f16_t, EPI, OUT_F32, 0, true>), dim3(mt * nt), dim3(256), 0, st, p, nt | (TILE_GROUP << 16));
+  }
+  OVG_CHECK_LAUNCH();
+  return OVG_OK;
+}
+int launch_linear_x3(const ovg_linear_params& p, hipStream_t st) {
+  const int big = choose_256(p.tile, true, p.M, p.N, p.K, true);
+  if (big < 0) return OVG_E_ARG;
+  switch (p.epilogue) {
+    case OVG_EPI_STORE: return p.out_f32 ? launch_linear_x3_one<OVG_EPI_STORE, true>(p, st, big) : launch_linear_x3_one<OVG_EPI_STORE, false>(p, st, big);
+    case OVG_EPI_GELU: return launch_linear_x3_one<OVG_EPI_GELU, false>(p, st, big);
+    case OVG_EPI_RES: return launch_linear_x3_one<OVG_EPI_RES, true>(p, st, big);
+    case OVG_EPI_PATCH: return launch_linear_x3_one<OVG_EPI_PATCH, true>(p, st, big);
+    default: return OVG_E_ARG;
+  }
+}
+
 }  // namespace
 
 extern "C" int ovg_linear(const ovg_linear_params* p, void* stream) {
@@ -870,6 +953,12 @@ extern "C" int ovg_linear(const ovg_linear_params* p, void* stream) {
     case OVG_BF16: return launch_linear<bf16_t>(*p, st);
     case OVG_F16: return launch_linear<f16_t>(*p, st);
     case OVG_F32: return launch_linear<float>(*p, st);
+    case OVG_F16X2: {
+      if (!p->x_lo || !p->w_lo || !aligned16(p->x_lo) || !aligned16(p->w_lo)) return OVG_E_ARG;
+      const bool out16 = (p->epilogue == OVG_EPI_STORE || p->epilogue == OVG_EPI_GELU) && !p->out_f32;
+      if (out16 && (!p->y_lo || !aligned16(p->y_lo))) return OVG_E_ARG;
+      return launch_linear_x3(*p, st);
+    }
     default: return OVG_E_DTYPE;
   }
 }
@@ -878,9 +967,13 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
   if (!p || !p->x || !p->w || !p->bias || !p->q || !p->k || !p->vt) return OVG_E_ARG;
   if (p->M <= 0 || p->M > (1 << 30) || p->seq <= 0 || p->M % p->seq != 0) return OVG_E_ARG;
   if (p->nq_pad < p->seq || p->nk_pad < p->seq || p->nk_pad % OVG_KV_TILE != 0) return OVG_E_ARG;
-  if (p->dtype != OVG_BF16 && p->dtype != OVG_F16 && p->dtype != OVG_F32) return OVG_E_DTYPE;
+  if (p->dtype != OVG_BF16 && p->dtype != OVG_F16 && p->dtype != OVG_F32 && p->dtype != OVG_F16X2) return OVG_E_DTYPE;
   const int64_t esz = p->dtype == OVG_F32 ? 4 : 2;
   if ((p->ldx * esz) % 16 || !aligned16(p->x) || !aligned16(p->w) || !aligned16(p->bias) || !aligned16(p->q) || !aligned16(p->k) || !aligned16(p->vt)) return OVG_E_ARG;
+  if (p->dtype == OVG_F16X2) {
+    if (!p->x_lo || !p->w_lo || !aligned16(p->x_lo) || !aligned16(p->w_lo)) return OVG_E_ARG;
+    if ((p->part != 2 && (!p->k_lo || !p->vt_lo || !aligned16(p->k_lo) || !aligned16(p->vt_lo))) || (p->part != 1 && (!p->q_lo || !aligned16(p->q_lo)))) return OVG_E_ARG;
+  }
   if (p->qk_norm && (!p->qn_w || !p->qn_b || !p->kn_w || !p->kn_b)) return OVG_E_ARG;
   if (p->rope) {
     if (!p->rope_cos || !p->rope_sin || p->tokens_per_view <= 0 || p->grid_w <= 0) return OVG_E_ARG;
@@ -902,6 +995,10 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
       const int ok = allow_big_lds(qkv256_kernel<bf16_t>, g256::LDS_BYTES + ROPE_LDS_BYTES);
       if (ok != OVG_OK) return ok;
       OVG_LAUNCH((qkv256_kernel<bf16_t>), grid2, dim3(512), g256::LDS_BYTES + ROPE_LDS_BYTES, st, *p, ntb, ntg2);
+    } else if (p->dtype == OVG_F16X2) {
+      const int ok = allow_big_lds(qkv256_kernel<f16_t, true>, g256::LDS_BYTES + ROPE_LDS_BYTES);
+      if (ok != OVG_OK) return ok;
+      OVG_LAUNCH((qkv256_kernel<f16_t, true>), grid2, dim3(512), g256::LDS_BYTES + ROPE_LDS_BYTES, st, *p, ntb, ntg2);
     } else {
       const int ok = allow_big_lds(qkv256_kernel<f16_t>, g256::LDS_BYTES + ROPE_LDS_BYTES);
       if (ok != OVG_OK) return ok;
@@ -918,6 +1015,7 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
   switch (p->dtype) {
     case OVG_BF16: OVG_LAUNCH((qkv_kernel<bf16_t>), grid, block, 0, st, *p, nt_begin, ntg); break;
     case OVG_F16: OVG_LAUNCH((qkv_kernel<f16_t>), grid, block, 0, st, *p, nt_begin, ntg); break;
+    case OVG_F16X2: OVG_LAUNCH((qkv_kernel<f16_t, true>), grid, block, 0, st, *p, nt_begin, ntg); break;
     default: OVG_LAUNCH((qkv_kernel<float>), grid, block, 0, st, *p, nt_begin, ntg); break;
   }
   OVG_CHECK_LAUNCH();

@@ -51,9 +51,12 @@ OVG_DEV void wait_tiles_in_flight(int n) {     // leave at most n k-stages (4 DM
 // leaves acc[nt][mt] = C[n = n0 + 64 wn + 16 nt + 4g + r][m = m0 + 128 wm + 16 mt + (lane & 15)]; with SWAP the MFMA
 // operands trade places and every 16 x 16 block comes out transposed: acc[nt][mt][r] = C[n = .. + 16 nt + (lane & 15)][m = .. + 16 mt + 4g + r]
 // (the V^T tiles of the QKV projection: a lane then owns 4 CONSECUTIVE tokens of one feature = one 8-byte store)
-template <typename T, bool SWAP = false>
+// X3 (OVG_F16X2): operands are (hi, lo) plane pairs and the ring streams 3 nk virtual k-stages -- x_lo * w_hi, x_hi * w_lo, x_hi * w_hi --
+// whose source planes are chosen per stage in stage(); everything else (ring, waits, ping-pong) is unchanged.
+template <typename T, bool SWAP = false, bool X3 = false>
 OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict__ W, int64_t ldw,
-                      int M, int N, int K, int m0, int n0, unsigned char* lds, f32x4 (&acc)[4][8]) {
+                      int M, int N, int K, int m0, int n0, unsigned char* lds, f32x4 (&acc)[4][8],
+                      const T* __restrict__ Xlo = nullptr, const T* __restrict__ Wlo = nullptr) {
   static_assert(sizeof(T) == 2, "16-bit operands");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,13 +75,23 @@ OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict_
     wg[i] = reinterpret_cast<const unsigned char*>(W + (int64_t)wr * ldw) + ch * 16;
     xg[i] = reinterpret_cast<const unsigned char*>(X + (int64_t)xr * ldx) + ch * 16;
   }
+  const int nk1 = (K * 2) / ROWB;
+  const int64_t dxl = X3 ? reinterpret_cast<const unsigned char*>(Xlo) - reinterpret_cast<const unsigned char*>(X) : 0;
+  const int64_t dwl = X3 ? reinterpret_cast<const unsigned char*>(Wlo) - reinterpret_cast<const unsigned char*>(W) : 0;
   auto stage = [&](int kt) {
     unsigned char* wb = lds + (kt & (SLOTS - 1)) * STAGE_B + wave * 32 * ROWB;   // wave-uniform destinations
     unsigned char* xb = wb + W_TILE;
+    int64_t xo = (int64_t)kt * ROWB, wo = xo;
+    if constexpr (X3) {
+      const int pass = kt >= 2 * nk1 ? 2 : (kt >= nk1 ? 1 : 0);
+      const int64_t kb = (int64_t)(kt - pass * nk1) * ROWB;
+      xo = kb + (pass == 0 ? dxl : 0);
+      wo = kb + (pass == 1 ? dwl : 0);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(wg[i] + (int64_t)kt * ROWB), (lptr_t)(wb + i * 16 * ROWB), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(xg[i] + (int64_t)kt * ROWB), (lptr_t)(xb + i * 16 * ROWB), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wg[i] + wo), (lptr_t)(wb + i * 16 * ROWB), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(xg[i] + xo), (lptr_t)(xb + i * 16 * ROWB), 16, 0, 0);
     }
   };
 #pragma unroll
@@ -86,7 +99,7 @@ OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict_
 #pragma unroll
     for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (K * 2) / ROWB;
+  const int nk = X3 ? 3 * nk1 : nk1;
   const int frag_off = lr * ROWB + (g ^ swz64(lr)) * 16;
   const int w_off = wn * 64 * ROWB + frag_off, x_off = W_TILE + wm * 128 * ROWB + frag_off;
   u32x4 a[4], b[8];

@@ -21,6 +21,7 @@ no 16-bit head error: 3.6 ms instead of 1.2 ms at 8 views).
 import torch
 import torch.nn as nn
 
+from . import lib as L
 from .aggregator import ZeroAggregator
 from .heads import CameraHead, DPTHead
 from .heads_hip import HipCameraHead, HipDPTHead
@@ -53,7 +54,7 @@ class OmniVGGT(nn.Module, _HubMixin):
         self._hip_cam = HipCameraHead(self.camera_head)
 
     def _camera(self, cam_tokens):
-        dt = self.aggregator.compute_dtype
+        dt = L.head_dtype(self.aggregator.compute_dtype)      # split-f16 aggregator: the heads run on the exact-f32 kernels
         toks = cam_tokens[-1]
         lowp = dt in (torch.bfloat16, torch.float16)
         if self.hip_heads and self.hip_camera_head and (lowp or self.hip_heads_f32) and toks.is_cuda and toks.shape[1] <= 4096:
@@ -61,7 +62,7 @@ class OmniVGGT(nn.Module, _HubMixin):
         return self.camera_head(cam_tokens)
 
     def _dpt(self, which, head, tokens, imgs32, patch_start_idx):
-        dt = self.aggregator.compute_dtype
+        dt = L.head_dtype(self.aggregator.compute_dtype)
         if self.hip_heads and imgs32.is_cuda and (dt in (torch.bfloat16, torch.float16) or self.hip_heads_f32):
             return self._hip_dpt[which](tokens, imgs32, patch_start_idx, dtype=dt)     # f32: exact-f32 MFMA convolutions (r03)
         return head(tokens, images=imgs32, patch_start_idx=patch_start_idx)
@@ -89,8 +90,8 @@ class OmniVGGT(nn.Module, _HubMixin):
         heads) f32 -- one safetensors file that from_packed() maps back without any conversion."""
         from safetensors.torch import save_file
         dt = self.aggregator.compute_dtype
-        if dt == torch.float32:
-            raise ValueError("packed files are for the 16-bit modes; the f32 mode loads the original checkpoint")
+        if dt is torch.float32 or L.is_split(dt):
+            raise ValueError("packed files are for the 16-bit modes; the f32 and split-f16 modes load the original checkpoint")
         tensors = {"aggregator." + k: v.detach().cpu().contiguous() for k, v in self.aggregator.export_packed(torch.device(device)).items()}
         for k, v in self.state_dict().items():
             if not k.startswith("aggregator."):

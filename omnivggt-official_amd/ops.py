@@ -29,14 +29,59 @@ def _chk_dev(*ts):
             raise L.OvgError("expected a HIP device tensor (the hot path has no CPU fallback)")
 
 
+class HiLo:
+    """A split-f16 tensor (L.F32X mode): two f16 planes of one allocation, value ~ hi + lo (include/omnivggt_hip.h, OVG_F16X2)."""
+    def __init__(self, planes):
+        self.planes, self.hi, self.lo = planes, planes[0], planes[1]      # planes: f16 [2, ...] contiguous
+
+    @property
+    def shape(self):
+        return self.hi.shape
+
+    @property
+    def device(self):
+        return self.hi.device
+
+    def stride(self, i):
+        return self.hi.stride(i)
+
+    def float(self):
+        """f32 value of the pair (tests)."""
+        return self.hi.float() + self.lo.float()
+
+    def rows(self, lo, hi):
+        return HiLo(self.planes[:, lo:hi])
+
+
+def empty_like_dtype(shape, dtype, device, zero=False):
+    """Activation / weight storage for `dtype`: a plain tensor, or a HiLo pair of f16 planes in the split-f16 mode."""
+    mk = torch.zeros if zero else torch.empty
+    if L.is_split(dtype):
+        return HiLo(mk((2,) + tuple(shape), device=device, dtype=torch.float16))
+    return mk(tuple(shape), device=device, dtype=dtype)
+
+
+def hi_lo(t):
+    """(tensor whose pointer goes into the ordinary field, tensor for the *_lo field or None)."""
+    return (t.hi, t.lo) if isinstance(t, HiLo) else (t, None)
+
+
+def to_hilo(x32):
+    """f32 tensor -> HiLo on the same device with the library's rounding (hi = f16(sat(x)), lo = f16(x - hi)); tests / tools."""
+    hi = x32.clamp(-65504.0, 65504.0).to(torch.float16)
+    lo = (x32 - hi.float()).clamp(-65504.0, 65504.0).to(torch.float16)
+    return HiLo(torch.stack([hi, lo]).contiguous())
+
+
 def layernorm(x, weight, bias, eps, dtype, out=None, out_f32=False):
     """x: f32 [rows, 1024] (row-strided view allowed) -> [rows,1024] in dtype (or f32)."""
     _chk_dev(x, weight, bias)
     rows = x.shape[0]
     if out is None:
-        out = torch.empty(rows, C, device=x.device, dtype=torch.float32 if out_f32 else dtype)
-    p = L.LayerNormParams(L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), L.ptr(weight), L.ptr(bias), rows, eps,
-                          L.dtype_code(dtype), 1 if out_f32 else 0)
+        out = torch.empty(rows, C, device=x.device, dtype=torch.float32) if out_f32 else empty_like_dtype((rows, C), dtype, x.device)
+    o_hi, o_lo = hi_lo(out)
+    p = L.LayerNormParams(L.ptr(x), x.stride(0), L.ptr(o_hi), o_hi.stride(0), L.ptr(weight), L.ptr(bias), rows, eps,
+                          L.dtype_code(dtype), 1 if out_f32 else 0, L.ptr(o_lo))
     L.call("ovg_layernorm", p, _stream())
     return out
 
@@ -44,15 +89,20 @@ def layernorm(x, weight, bias, eps, dtype, out=None, out_f32=False):
 def linear(x, w, bias, dtype, epilogue=L.EPI_STORE, out=None, out_f32=False, res=None, gamma=None, inject=None,
            inj_period=0, table=None, p0=0, p1=0, row_off=0, out_rows=None, tile=L.TILE_AUTO):
     """y = epilogue(x @ w.T + bias); x [M,K], w [N,K] in dtype."""
-    _chk_dev(x, w, bias, res, gamma, inject, table, out)
+    (x, x_lo), (w, w_lo) = hi_lo(x), hi_lo(w)
+    _chk_dev(x, w, bias, res, gamma, inject, table)
     M, K = x.shape
     N = w.shape[0]
     f32_out = out_f32 or epilogue in (L.EPI_RES, L.EPI_PATCH)
     if out is None:
-        out = torch.empty(out_rows if out_rows is not None else M, N, device=x.device, dtype=torch.float32 if f32_out else dtype)
+        rows = out_rows if out_rows is not None else M
+        out = torch.empty(rows, N, device=x.device, dtype=torch.float32) if f32_out else empty_like_dtype((rows, N), dtype, x.device)
+    o_hi, o_lo = hi_lo(out)
+    _chk_dev(o_hi)
     p = L.LinearParams()
     p.x, p.ldx, p.w, p.ldw, p.bias = L.ptr(x), x.stride(0), L.ptr(w), w.stride(0), L.ptr(bias)
-    p.y, p.ldy, p.M, p.N, p.K = L.ptr(out), out.stride(0), M, N, K
+    p.y, p.ldy, p.M, p.N, p.K = L.ptr(o_hi), o_hi.stride(0), M, N, K
+    p.x_lo, p.w_lo, p.y_lo = L.ptr(x_lo), L.ptr(w_lo), L.ptr(o_lo)
     p.dtype, p.epilogue, p.out_f32 = L.dtype_code(dtype), epilogue, 1 if f32_out else 0
     if res is not None:
         p.res, p.ldres = L.ptr(res), res.stride(0)
@@ -66,7 +116,7 @@ def vt_index(n_pad, dtype, device="cpu"):
     """Column permutation of a V^T row: idx[pos] = key stored at column pos. 16-bit dtypes: inside every block of 32 keys
     pos = 8 g + 4 h + i holds key 16 h + 4 g + i (the PV fragment order, csrc/ovg_common.h vt_pos16); f32: identity."""
     pos = torch.arange(n_pad, device=device)
-    if dtype == torch.float32:
+    if dtype is torch.float32:
         return pos
     k = pos & 31
     return (pos & ~31) | (((k >> 2) & 1) << 4) | (((k >> 3) & 3) << 2) | (k & 3)
@@ -93,19 +143,21 @@ def alloc_qkv(BH, nq, nk, dtype, device):
     """Zero-filled head-major buffers q [BH,nq_pad,64], k [BH,nk_pad,64], vt [BH,64,nk_pad] (16-bit vt rows hold their keys in
     the vt_index order: fill / read them with set_vt / get_vt when they do not come from ovg_qkv)."""
     nq_pad, nk_pad = pad_to(nq, KV_TILE), pad_to(nk, KV_TILE)
-    q = torch.zeros(BH, nq_pad, D, device=device, dtype=dtype)
-    k = torch.zeros(BH, nk_pad, D, device=device, dtype=dtype)
-    vt = torch.zeros(BH, D, nk_pad, device=device, dtype=dtype)
+    q = empty_like_dtype((BH, nq_pad, D), dtype, device, zero=True)      # split-f16 mode: HiLo pairs
+    k = empty_like_dtype((BH, nk_pad, D), dtype, device, zero=True)
+    vt = empty_like_dtype((BH, D, nk_pad), dtype, device, zero=True)
     return q, k, vt
 
 
 def qkv(x, w, bias, seq, dtype, q, k, vt, qk_norm=None, rope=None, tokens_per_view=1374, grid_w=37, n_special=5,
         q_scale=0.125 * 1.4426950408889634, qk_eps=1e-5, part=0, tile=L.TILE_AUTO):
     """Fused QKV projection.  qk_norm = (qn_w, qn_b, kn_w, kn_b) or None; rope = (cos, sin) or None."""
+    (x, x_lo), (w, w_lo), (q, q_lo), (k, k_lo), (vt, vt_lo) = hi_lo(x), hi_lo(w), hi_lo(q), hi_lo(k), hi_lo(vt)
     _chk_dev(x, w, bias, q, k, vt)
     p = L.QkvParams()
     p.x, p.ldx, p.w, p.bias = L.ptr(x), x.stride(0), L.ptr(w), L.ptr(bias)
     p.q, p.k, p.vt = L.ptr(q), L.ptr(k), L.ptr(vt)
+    p.x_lo, p.w_lo, p.q_lo, p.k_lo, p.vt_lo = L.ptr(x_lo), L.ptr(w_lo), L.ptr(q_lo), L.ptr(k_lo), L.ptr(vt_lo)
     p.M, p.seq, p.nq_pad, p.nk_pad, p.dtype = x.shape[0], seq, q.shape[1], k.shape[1], L.dtype_code(dtype)
     if qk_norm is not None:
         p.qk_norm = 1
@@ -141,24 +193,31 @@ def alloc_split_ws(plan, device):
             torch.empty(plan["lse_bytes"] // 4, device=device, dtype=torch.float32))
 
 
-def flash_attn(q, segments, nq, dtype, out=None, variant=0, kv_heads=0, head_major=False, lse=None, kv_splits=0, split_ws=None):
+def flash_attn(q, segments, nq, dtype, out=None, variant=0, kv_heads=0, head_major=False, lse=None, kv_splits=0, split_ws=None, fallback_count=None):
     """q [BH,nq_pad,64]; segments: list of (k [BHkv,nk_pad,64], vt [BHkv,64,nk_pad], nk).
     Returns out [B*nq, 1024] token-major, or with head_major=True out [BH, nq_pad, 64].
     kv_heads > 0: the segments hold kv_heads heads and batch entry bh attends to head bh % kv_heads
     (head-parallel sharding: the BH entries are (source rank, head) pairs).
     lse: optional f32 [BH, nq_pad] receiving log2(sum_k exp2(logit)) over the keys of this call (see attn_merge).
     kv_splits / split_ws = (ws_part, ws_lse) from alloc_split_ws(attn_plan(...)): split-KV for launches that do not fill the
-    chip evenly (kv_splits 0 = library decides, and only splits when split_ws is given; 1 = never; 2..8 = force)."""
+    chip evenly (kv_splits 0 = library decides, and only splits when split_ws is given; 1 = never; 2..8 = force).
+    fallback_count: optional int32 device tensor [1]: workgroups of the speculative bf16 kernels that re-ran (telemetry).
+    Split-f16 mode (dtype = L.F32X): q / k / vt / out are HiLo pairs."""
+    q, q_lo = hi_lo(q)
     _chk_dev(q)
     BH = q.shape[0]
     if out is None:
-        out = (torch.empty(BH, q.shape[1], D, device=q.device, dtype=dtype) if head_major
-               else torch.empty((BH // H) * nq, C, device=q.device, dtype=dtype))
+        out = empty_like_dtype((BH, q.shape[1], D) if head_major else ((BH // H) * nq, C), dtype, q.device)
+    ret = out
+    out, out_lo = hi_lo(out)
     p = L.AttnParams()
     p.q, p.nq, p.nq_pad, p.nseg = L.ptr(q), nq, q.shape[1], len(segments)
+    p.q_lo, p.out_lo = L.ptr(q_lo), L.ptr(out_lo)
     for i, (k, vt, nk) in enumerate(segments):
+        (k, k_lo), (vt, vt_lo) = hi_lo(k), hi_lo(vt)
         _chk_dev(k, vt)
         p.seg[i].k, p.seg[i].vt, p.seg[i].nk, p.seg[i].nk_pad = L.ptr(k), L.ptr(vt), nk, k.shape[1]
+        p.seg[i].k_lo, p.seg[i].vt_lo = L.ptr(k_lo), L.ptr(vt_lo)
     p.out, p.BH, p.dtype, p.variant, p.kv_heads = L.ptr(out), BH, L.dtype_code(dtype), variant, kv_heads
     if head_major:
         p.ldo, p.out_bh_stride = out.stride(1), out.stride(0)
@@ -174,8 +233,11 @@ def flash_attn(q, segments, nq, dtype, out=None, variant=0, kv_heads=0, head_maj
         _chk_dev(*split_ws)
         p.ws_part, p.ws_lse = L.ptr(split_ws[0]), L.ptr(split_ws[1])
         p.ws_part_bytes, p.ws_lse_bytes = nbytes(split_ws[0]), nbytes(split_ws[1])
+    if fallback_count is not None:
+        _chk_dev(fallback_count)
+        p.fallback_count = L.ptr(fallback_count)
     L.call("ovg_flash_attn", p, _stream())
-    return out
+    return ret
 
 
 def attn_merge(a, lse_a, b, lse_b, dtype, out=None):
@@ -196,8 +258,9 @@ def pack_weights(src, dtype, k_pad=None):
     s2 = src.detach().reshape(src.shape[0], -1).float().contiguous()
     rows, k = s2.shape
     k_pad = k if k_pad is None else k_pad
-    out = torch.empty(rows, k_pad, device=src.device, dtype=dtype)
-    p = L.PackWeightsParams(L.ptr(s2), s2.stride(0), L.ptr(out), out.stride(0), rows, k, k_pad, L.dtype_code(dtype))
+    out = empty_like_dtype((rows, k_pad), dtype, src.device)
+    o_hi, o_lo = hi_lo(out)
+    p = L.PackWeightsParams(L.ptr(s2), s2.stride(0), L.ptr(o_hi), o_hi.stride(0), rows, k, k_pad, L.dtype_code(dtype), L.ptr(o_lo))
     L.call("ovg_pack_weights", p, _stream())
     return out
 
@@ -228,9 +291,11 @@ def im2col_rgb(images, dtype, k_pad=640, mean=(0.485, 0.456, 0.406), std=(0.229,
     """images f32 [V,3,H,W] -> [V*gh*gw, k_pad] normalised patches."""
     _chk_dev(images)
     V, Cc, Hp, Wp = images.shape
-    out = torch.empty(V * (Hp // 14) * (Wp // 14), k_pad, device=images.device, dtype=dtype)
+    out = empty_like_dtype((V * (Hp // 14) * (Wp // 14), k_pad), dtype, images.device)
+    o_hi, o_lo = hi_lo(out)
     p = L.Im2colParams()
-    p.img, p.out, p.k_pad, p.V, p.C, p.Hpx, p.Wpx = L.ptr(images), L.ptr(out), k_pad, V, Cc, Hp, Wp
+    p.img, p.out, p.k_pad, p.V, p.C, p.Hpx, p.Wpx = L.ptr(images), L.ptr(o_hi), k_pad, V, Cc, Hp, Wp
+    p.out_lo = L.ptr(o_lo)
     p.dtype, p.mode = L.dtype_code(dtype), 0
     for i in range(3):
         p.mean[i], p.std[i] = mean[i], std[i]
@@ -254,9 +319,11 @@ def im2col_depth(depth, mask, stats, views_per_batch, dtype, k_pad=448):
     """depth, mask f32 [V,H,W]; stats f64 [B,2] -> [V*gh*gw, k_pad] (channels: normalised depth, mask)."""
     _chk_dev(depth, mask, stats)
     V, Hp, Wp = depth.shape
-    out = torch.empty(V * (Hp // 14) * (Wp // 14), k_pad, device=depth.device, dtype=dtype)
+    out = empty_like_dtype((V * (Hp // 14) * (Wp // 14), k_pad), dtype, depth.device)
+    o_hi, o_lo = hi_lo(out)
     p = L.Im2colParams()
-    p.img, p.img2, p.out, p.k_pad, p.V, p.C, p.Hpx, p.Wpx = L.ptr(depth), L.ptr(mask), L.ptr(out), k_pad, V, 2, Hp, Wp
+    p.img, p.img2, p.out, p.k_pad, p.V, p.C, p.Hpx, p.Wpx = L.ptr(depth), L.ptr(mask), L.ptr(o_hi), k_pad, V, 2, Hp, Wp
+    p.out_lo = L.ptr(o_lo)
     p.dtype, p.mode, p.depth_stats, p.views_per_batch = L.dtype_code(dtype), 1, L.ptr(stats), views_per_batch
     L.call("ovg_im2col", p, _stream())
     return out

@@ -209,7 +209,8 @@ def test_attn(quick):
     g = torch.Generator().manual_seed(5)
     for name, dt in DT.items():
         shapes = [("n1374_bh32", 32, 1374, [1374]), ("n2748_2seg", 16, 2748 // 2, [1374, 1374]),
-                  ("n700_ragged_seg", 16, 700, [100, 333, 64]), ("n300_seg", 16, 300, [130, 70])]
+                  ("n700_ragged_seg", 16, 700, [100, 333, 64]), ("n300_seg", 16, 300, [130, 70]),
+                  ("n500_short_segs", 16, 500, [40, 64, 7, 192, 129])]      # segments shorter than one key tile, exact tiles, a 1-key tail
         variants = (1,) if name == "f32" else ATTN16_VARIANTS
         if quick:
             shapes = shapes[:2]
@@ -275,6 +276,143 @@ def test_attn(quick):
                 out = ops.flash_attn(qd, [(kd, vtd, nk)], nq, dt, variant=variant)
                 report("attn_%s_%s_rescale_v%d" % (name, cname, variant), out, ref, TOL[name])
 
+
+
+def test_f32x(quick):
+    """The split-f16 mode (OVG_F16X2, L.F32X): every 16-bit tensor is a (hi, lo) pair of f16 planes and every contraction three f16
+    MFMAs. Inputs are PLAIN f32 values (split by the library's own rounding rule, ops.to_hilo / ovg_pack_weights); the references are
+    float64 evaluations of the same f32 values, so the tolerances bound the whole mode -- operand split (2^-22), dropped lo*lo term,
+    f32 accumulation -- not a twin with matching rounding points. Gates: 1e-5 max-rel (the bf16 / f16 / f32 gates are 2e-2 / 4e-3 / 2e-5)."""
+    dt, TOLX = L.F32X, 1e-5
+    g = torch.Generator().manual_seed(41)
+    d64 = lambda t: t.double()
+    dev = lambda t: t.to(DEV)
+    # --- split rule: library pack == ops.to_hilo, reconstruction error
+    w32 = rnd(384, 1024, g=g) * 0.03
+    pk = ops.pack_weights(dev(w32), dt)
+    th = ops.to_hilo(w32)
+    report("f32x_pack_weights.hi_bits", pk.hi.float(), th.hi.float(), 0.0)
+    report("f32x_pack_weights.lo_bits", pk.lo.float(), th.lo.float(), 0.0)
+    report("f32x_pack_weights.value", d64(pk.hi.cpu()) + d64(pk.lo.cpu()), d64(w32), 4e-7)
+    pkp = ops.pack_weights(dev(rnd(16, 588, g=g)), dt, k_pad=640)
+    report("f32x_pack_weights.pad_zero", pkp.hi[:, 588:].float().abs() + pkp.lo[:, 588:].float().abs(), torch.zeros(16, 52), 0.0)
+    # --- LayerNorm -> HiLo
+    big = rnd(1374 + 3, 2048, g=g, scale=2.0) + 0.3
+    w, b = rnd(1024, g=g) * 0.1 + 1, rnd(1024, g=g) * 0.1
+    y = ops.layernorm(dev(big)[:, 1024:], dev(w), dev(b), 1e-5, dt)
+    report("f32x_layernorm", d64(y.hi.cpu()) + d64(y.lo.cpu()), F.layer_norm(d64(big[:, 1024:]), (1024,), d64(w), d64(b), 1e-5), 2e-6)
+    # --- linear, every epilogue, both tile sizes
+    cases = [(300, 256, 128, L.TILE_AUTO), (1374 * 2, 1024, 1024, L.TILE_AUTO), (1374 * 2 + 77, 1024, 1024, L.TILE_256)]
+    if not quick:
+        cases += [(1374 * 2 + 77, 4096, 1024, L.TILE_256), (700, 1024, 4096, L.TILE_256), (21000, 1024, 1024, L.TILE_AUTO)]
+    for (M, N, K, tile) in cases:
+        tag = "%dx%dx%d_t%d" % (M, N, K, tile)
+        x32, w32, bias = rnd(M, K, g=g), rnd(N, K, g=g) * 0.05, rnd(N, g=g)
+        base = d64(x32) @ d64(w32).t() + d64(bias)
+        xh, wh, bd = ops.to_hilo(dev(x32)), ops.pack_weights(dev(w32), dt), dev(bias)
+        y = ops.linear(xh, wh, bd, dt, tile=tile)
+        report("f32x_linear_store_" + tag, d64(y.hi.cpu()) + d64(y.lo.cpu()), base, TOLX)
+        y = ops.linear(xh, wh, bd, dt, out_f32=True, tile=tile)
+        report("f32x_linear_store_f32out_" + tag, y, base, TOLX)
+        y = ops.linear(xh, wh, bd, dt, epilogue=L.EPI_GELU, tile=tile)
+        report("f32x_linear_gelu_" + tag, d64(y.hi.cpu()) + d64(y.lo.cpu()), F.gelu(base), TOLX)
+        res, gamma, per = rnd(M, 2 * N, g=g), rnd(N, g=g), 137
+        inj = rnd((M + per - 1) // per, N, g=g)
+        ref = d64(res[:, N:]) + d64(gamma) * base
+        out = torch.zeros(M, 2 * N, device=DEV)
+        ops.linear(xh, wh, bd, dt, epilogue=L.EPI_RES, out=out[:, :N], res=dev(res)[:, N:], gamma=dev(gamma), tile=tile)
+        report("f32x_linear_res_" + tag, out[:, :N], ref, TOLX)
+        if N == 1024:
+            ref2 = ref.clone()
+            ref2[::per] += d64(inj[: ref2[::per].shape[0]])
+            ops.linear(xh, wh, bd, dt, epilogue=L.EPI_RES, out=out[:, :N], res=dev(res)[:, N:], gamma=dev(gamma), inject=dev(inj), inj_period=per, tile=tile)
+            report("f32x_linear_res_inject_" + tag, out[:, :N], ref2, TOLX)
+    p0, p1, N, K = 100, 105, 1024, 640
+    x32, w32, bias, table = rnd(2 * p0, K, g=g), rnd(N, K, g=g) * 0.05, rnd(N, g=g), rnd(p0 + 1, N, g=g)
+    base = d64(x32) @ d64(w32).t() + d64(bias)
+    ref = torch.zeros(2 * p1, N, dtype=torch.float64)
+    for v in range(2):
+        ref[v * p1 + 5: v * p1 + 5 + p0] = base[v * p0:(v + 1) * p0] + d64(table[1:])
+    out = torch.zeros(2 * p1, N, device=DEV)
+    ops.linear(ops.to_hilo(dev(x32)), ops.pack_weights(dev(w32), dt), dev(bias), dt, epilogue=L.EPI_PATCH, out=out, table=dev(table), p0=p0, p1=p1, row_off=5)
+    report("f32x_linear_patch", out, ref, TOLX)
+    # --- im2col -> HiLo (against the f32 kernel's output)
+    imgs = torch.rand(2, 3, 56, 70, generator=g)
+    c32 = ops.im2col_rgb(dev(imgs), torch.float32)
+    cx = ops.im2col_rgb(dev(imgs), dt)
+    report("f32x_im2col_rgb", d64(cx.hi.cpu()) + d64(cx.lo.cpu()), d64(c32.cpu()), 4e-7)
+    # --- fused QKV (q/k-norm + RoPE), frame and global sequences, both tile sizes
+    tpv, gw = 1374, 37
+    cos, sin = orc.rope_tables(38)
+    cos16, sin16 = dev(cos[:, :16].contiguous()), dev(sin[:, :16].contiguous())
+    for mode, nviews, tile in (("frame", 2, L.TILE_AUTO), ("global", 2, L.TILE_AUTO), ("global", 2, L.TILE_256)):
+        M = nviews * tpv
+        seq = tpv if mode == "frame" else M
+        x32, w32, bias = rnd(M, 1024, g=g), rnd(3072, 1024, g=g) * 0.03, rnd(3072, g=g) * 0.1
+        qn = [rnd(64, g=g) * 0.1 + 1.5, rnd(64, g=g) * 0.1, rnd(64, g=g) * 0.1 + 1.5, rnd(64, g=g) * 0.1]
+        for vn, qk_norm, rope in (("norm_rope", qn, (cos, sin)), ("plain", None, None)):
+            qr, kr, vr = qkv_reference(d64(x32), d64(w32), d64(bias), seq, None if qk_norm is None else [d64(t) for t in qk_norm],
+                                       None if rope is None else (d64(rope[0]), d64(rope[1])), tpv, gw)
+            BH = (M // seq) * 16
+            q, k, vt = ops.alloc_qkv(BH, seq, seq, dt, DEV)
+            ops.qkv(ops.to_hilo(dev(x32)), ops.pack_weights(dev(w32), dt), dev(bias), seq, dt, q, k, vt,
+                    qk_norm=None if qk_norm is None else [dev(t) for t in qk_norm], rope=None if rope is None else (cos16, sin16), tile=tile)
+            val = lambda h: d64(h.hi.cpu()) + d64(h.lo.cpu())
+            vtn = d64(ops.get_vt(vt.hi).cpu()) + d64(ops.get_vt(vt.lo).cpu())
+            report("f32x_qkv_%s_%s_t%d.q" % (mode, vn, tile), val(q)[:, :seq], qr.reshape(BH, seq, 64), TOLX)
+            report("f32x_qkv_%s_%s_t%d.k" % (mode, vn, tile), val(k)[:, :seq], kr.reshape(BH, seq, 64), TOLX)
+            report("f32x_qkv_%s_%s_t%d.vt" % (mode, vn, tile), vtn[:, :, :seq], vr.reshape(BH, seq, 64).transpose(1, 2), TOLX)
+            if not (float(val(q)[:, seq:].abs().max()) == 0.0 and float(vtn[:, :, seq:].abs().max()) == 0.0):
+                print("[FAIL] f32x qkv padding was written")
+                results.append({"name": "f32x_qkv_padding", "ok": False, "rel": float("nan")})
+    # --- flash attention on (hi, lo) planes: single / multi / ragged segments, forced rescale, log-sum-exp
+    def run_attn(tag, BH, nq, q32, ks32, vs32, tol=TOLX, want_lse=False):
+        ref = attn_reference(d64(q32), torch.cat([d64(t) for t in ks32], 1), torch.cat([d64(t) for t in vs32], 1))
+        ref_tok = ref.reshape(BH // 16, 16, nq, 64).permute(0, 2, 1, 3).reshape(-1, 1024)
+        qd, _, _ = ops.alloc_qkv(BH, nq, 64, dt, DEV)
+        qh = ops.to_hilo(dev(q32))
+        qd.hi[:, :nq], qd.lo[:, :nq] = qh.hi, qh.lo
+        segs = []
+        for kk, vv in zip(ks32, vs32):
+            nk = kk.shape[1]
+            _, kd, vtd = ops.alloc_qkv(BH, 64, nk, dt, DEV)
+            kh, vh = ops.to_hilo(dev(kk)), ops.to_hilo(dev(vv.transpose(1, 2).contiguous()))
+            kd.hi[:, :nk], kd.lo[:, :nk] = kh.hi, kh.lo
+            ops.set_vt(vtd.hi, vh.hi)
+            ops.set_vt(vtd.lo, vh.lo)
+            segs.append((kd, vtd, nk))
+        lse = torch.zeros(BH, qd.shape[1], device=DEV) if want_lse else None
+        out = ops.flash_attn(qd, segs, nq, dt, lse=lse)
+        report("f32x_attn_" + tag, d64(out.hi.cpu()) + d64(out.lo.cpu()), ref_tok, tol)
+        if want_lse:
+            s2 = d64(q32) @ torch.cat([d64(t) for t in ks32], 1).transpose(-1, -2)
+            report("f32x_attn_" + tag + ".lse", lse[:, :nq], torch.logsumexp(s2 * math.log(2.0), -1) / math.log(2.0), 5e-6)
+    shapes = [("n1374_bh32", 32, 1374, [1374]), ("n2748_2seg", 16, 1374, [1374, 1374]), ("n700_ragged_seg", 16, 700, [100, 333, 64]), ("n300_seg", 16, 300, [130, 70]),
+              ("n500_short_segs", 16, 500, [40, 64, 7, 192, 129])]
+    for cname, BH, nq, nks in (shapes[:2] if quick else shapes):
+        run_attn(cname, BH, nq, rnd(BH, nq, 64, g=g) * 1.2, [rnd(BH, nk, 64, g=g) for nk in nks], [rnd(BH, nk, 64, g=g) for nk in nks], want_lse=(cname in ("n300_seg", "n500_short_segs") or quick))
+    for cname, spike in (("spike", 6.0), ("spike_small", 1.0), ("ramp", 0.0)):
+        BH, nq, nk = 16, 128, 640
+        q32, k32, v32 = rnd(BH, nq, 64, g=g), rnd(BH, nk, 64, g=g), rnd(BH, nk, 64, g=g)
+        if spike:
+            k32[:, 500] = q32[:, 7] * spike
+        else:
+            k32 = k32 + q32[:, 3:4] * torch.linspace(0, 3, nk).view(1, nk, 1)
+        run_attn(cname + "_rescale", BH, nq, q32, [k32], [v32])
+    if not quick:      # one global-attention launch at the 8-view key count (10 992 keys: 172 tiles), sampled rows checked in float64
+        BH, n = 16, 8 * 1374
+        q32, k32, v32 = rnd(BH, n, 64, g=g) * 1.2, rnd(BH, n, 64, g=g), rnd(BH, n, 64, g=g)
+        qd, kd, vtd = ops.alloc_qkv(BH, n, n, dt, DEV)
+        for dst, src in ((qd, q32), (kd, k32)):
+            h = ops.to_hilo(dev(src))
+            dst.hi[:, :n], dst.lo[:, :n] = h.hi, h.lo
+        vh = ops.to_hilo(dev(v32.transpose(1, 2).contiguous()))
+        ops.set_vt(vtd.hi, vh.hi)
+        ops.set_vt(vtd.lo, vh.lo)
+        out = ops.flash_attn(qd, [(kd, vtd, n)], n, dt)
+        rows = torch.tensor([0, 1, 255, 256, 257, 4095, 5000, n - 257, n - 2, n - 1])
+        ref = attn_reference(d64(q32[:, rows]), d64(k32), d64(v32)).permute(1, 0, 2).reshape(len(rows), 1024)
+        report("f32x_attn_global_n10992_rows", (d64(out.hi[rows.to(DEV)].cpu()) + d64(out.lo[rows.to(DEV)].cpu())), ref, TOLX)
 
 
 def test_heads(quick):
@@ -830,7 +968,7 @@ def main():
     tests = {"probe": test_probe, "layernorm": test_layernorm, "linear": lambda: test_linear(args.quick), "qkv": lambda: test_qkv(args.quick),
              "attn": lambda: test_attn(args.quick), "embed": test_embed, "block": lambda: test_block(args.quick),
              "heads": lambda: test_heads(args.quick), "gemm256": lambda: test_gemm256(args.quick), "attn_big": lambda: test_attn_big(args.quick),
-             "lse_merge": test_attn_lse_merge, "camera": lambda: test_camera_head(timing=True)}
+             "lse_merge": test_attn_lse_merge, "camera": lambda: test_camera_head(timing=True), "f32x": lambda: test_f32x(args.quick)}
     for name, fn in tests.items():
         if args.only and name not in args.only.split(","):
             continue

@@ -101,6 +101,65 @@ def test_argument_validation_without_gpu():
     assert lib.ovg_camera_head_workspace_bytes(8, 99) == -1 and lib.ovg_camera_head_workspace_bytes(0, L.OVG_BF16) == -1
 
 
+def test_split_f16_mode_contract_on_cpu():
+    """OVG_F16X2 / lib.F32X (ABI 8): the split rule, the dtype plumbing and the argument validation of the entries that take (hi, lo)
+    plane pairs -- everything that can be checked without a device."""
+    from omnivggt_official_amd import ops
+    assert L.dtype_code(L.F32X) == L.OVG_F16X2 == 3 and L.storage_dtype(L.F32X) is torch.float16 and L.head_dtype(L.F32X) is torch.float32
+    assert L.storage_dtype(torch.bfloat16) is torch.bfloat16 and L.head_dtype(torch.float16) is torch.float16 and repr(L.F32X) == "f32x"
+    # split rule: hi = f16(sat(x)), lo = f16(x - hi): 2^-22 relative while lo is a normal f16, 2^-25 absolute below, saturating above
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([torch.randn(4096, generator=g) * s for s in (1e-3, 0.02, 1.0, 50.0, 3e3)] + [torch.tensor([0.0, 65504.0, 70000.0, -1e5, 6e-8, 1e-9])])
+    h = ops.to_hilo(x)
+    assert h.hi.dtype == h.lo.dtype == torch.float16 and h.planes.shape == (2,) + tuple(x.shape)
+    err = (h.float().double() - x.double()).abs()
+    bound = torch.maximum(x.double().abs() * 2.0 ** -21, torch.full_like(err, 2.0 ** -24))
+    ok = x.abs() <= 65504.0 * (1 + 2.0 ** -11)
+    assert bool((err[ok] <= bound[ok]).all()), float((err[ok] / bound[ok]).max())
+    assert torch.isfinite(h.hi).all() and torch.isfinite(h.lo).all()                 # saturating, never inf
+    assert abs(float(h.float()[-4]) - 70000.0) <= 32.0                                # hi = 65504, lo carries the rest
+    # argument validation (host side, before any launch)
+    lib = L.load()
+    fake = 0x10000
+    p = L.LinearParams()
+    p.x, p.w, p.y, p.M, p.N, p.K, p.ldx, p.ldw, p.ldy, p.dtype = fake, fake, fake, 128, 128, 128, 128, 128, 128, L.OVG_F16X2
+    assert lib.ovg_linear(ctypes.byref(p), None) == -1                               # lo planes of x / w missing
+    p.x_lo, p.w_lo = fake, fake
+    assert lib.ovg_linear(ctypes.byref(p), None) == -1                               # 16-bit output needs y_lo
+    p.y_lo = fake + 8
+    assert lib.ovg_linear(ctypes.byref(p), None) == -1                               # misaligned
+    q = L.QkvParams()
+    q.x, q.w, q.bias, q.q, q.k, q.vt = (fake,) * 6
+    q.M, q.seq, q.nq_pad, q.nk_pad, q.ldx, q.dtype = 128, 128, 128, 128, 1024, L.OVG_F16X2
+    assert lib.ovg_qkv(ctypes.byref(q), None) == -1
+    a = L.AttnParams()
+    a.q, a.out, a.nq, a.nq_pad, a.BH, a.nseg, a.ldo, a.dtype = fake, fake, 64, 64, 16, 1, 1024, L.OVG_F16X2
+    a.seg[0].k, a.seg[0].vt, a.seg[0].nk, a.seg[0].nk_pad = fake, fake, 64, 64
+    assert lib.ovg_flash_attn(ctypes.byref(a), None) == -1                           # q_lo / out_lo / segment lo planes missing
+    a.q_lo, a.out_lo, a.seg[0].k_lo, a.seg[0].vt_lo, a.kv_splits = fake, fake, fake, fake, 2
+    assert lib.ovg_flash_attn(ctypes.byref(a), None) == -4                           # no split-KV in the split-f16 mode
+    a.kv_splits, a.kv_heads = 0, 2
+    assert lib.ovg_flash_attn(ctypes.byref(a), None) == -4                           # no head-parallel form either
+    plan = ops.attn_plan(16, 87936, [87936], L.F32X)
+    assert plan["splits"] == 1 and plan["q_tile"] == 256 and plan["tail_q_tile"] == 0 and plan["part_bytes"] == 0
+    ws = ops.block_workspace_bytes(8 * 1374, 1374, L.F32X)                           # bytes of ONE plane of each scratch tensor
+    assert ws["xn"] == 8 * 1374 * 1024 * 2 and ws["hid"] == 8 * 1374 * 4096 * 2
+    for cls, fields in ((L.LayerNormParams, ("y_lo",)), (L.PackWeightsParams, ("dst_lo",)), (L.Im2colParams, ("out_lo",)),
+                        (L.BlockWeights, ("qkv_w_lo", "proj_w_lo", "fc1_w_lo", "fc2_w_lo")), (L.BlockParams, ("ws_xn_lo", "ws_hid_lo", "attn_fallback_count")),
+                        (L.AttnParams, ("q_lo", "out_lo", "fallback_count")), (L.KvSegment, ("k_lo", "vt_lo"))):
+        names = [f for f, _ in cls._fields_]
+        assert all(f in names for f in fields), cls
+    # the aggregator takes the mode by sentinel or by name and refuses what the mode does not support
+    with torch.device("meta"):
+        agg = ZeroAggregator(depth=1, dino_depth=1, compute_dtype="f32x")
+    assert agg.compute_dtype is L.F32X
+    agg.set_compute_dtype(torch.float32)
+    agg.set_compute_dtype("f32x")
+    assert agg.compute_dtype is L.F32X
+    with pytest.raises(ValueError):
+        agg.set_compute_dtype(torch.float64)
+
+
 def test_block_workspace_query_matches_the_python_allocation():
     """ovg_block_workspace_bytes (caller-provided workspace with a size query) vs what Workspace allocates."""
     from omnivggt_official_amd import ops

@@ -90,6 +90,14 @@ def test_attention_lse_output_and_merge_and_weight_pack():
     _assert_clean()
 
 
+def test_split_f16_mode_kernels_vs_float64():
+    """OVG_F16X2 ("f32x", the <= 1e-4 mode with throughput): pack / LayerNorm / im2col splits, every GEMM epilogue on both tile sizes,
+    the fused QKV epilogue and the three-MFMA flash attention (segments, ragged tails, forced rescale, log-sum-exp), each within 1e-5
+    max-rel of a float64 evaluation of the same f32 inputs."""
+    st.test_f32x(False)
+    _assert_clean()
+
+
 def test_loaded_library_is_the_in_tree_one():
     import os
     assert os.path.samefile(L.LIB_PATH, os.path.join(os.path.dirname(L.__file__), "libomnivggt_hip.so"))

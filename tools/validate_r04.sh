@@ -22,6 +22,20 @@ for stage in "$@"; do
       (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_S$v" -- python "$R/bench.py" --views $v --steps 4 --warmup 1 --no-cpu-baseline --no-parity --no-secondary > "$O/prof_S$v.log" 2>&1)
       f=$(find "$O/prof_S$v" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$O/bench_S${v}_kernel_stats.csv" && head -12 "$f" | cut -c1-200
       find "$O/prof_S$v" -name "*.csv" -size +1M -delete ;;
+    f32x_kernels) (timeout 900 python tests/gpu_selftest.py --only f32x 2>&1 | tail -120) | tee "$O/f32x_selftest.log" | grep -E "FAIL|SELFTEST|Error|error" | head -40 ;;
+    f32x_agg)   (timeout 1500 python -m pytest tests/test_gpu_aggregator.py -m gpu -q -s -k "f32x" 2>&1 | grep -E "max-rel|passed|failed|Error|error|f32x full" | tail -40) | tee "$O/f32x_agg.log" ;;
+    bench_f32x) timeout 1200 python bench.py --dtype f32x --steps 3 --warmup 1 --no-cpu-baseline 2>"$O/bench_f32x.err" | tail -1 | tee "$O/bench_f32x_line.json" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('f32x frames/s', d['value'], 'ms', d['ms_per_step'], 'attn frac', d['roofline']['frac'], 'achieved', d['roofline']['achieved'], '| S8', d.get('secondary',{}).get('frames_per_s'), '| parity', {k: v.get('max_rel') for k, v in d.get('parity',{}).items() if isinstance(v, dict)})" || tail -20 "$O/bench_f32x.err" ;;
+    bench_f32)  timeout 1200 python bench.py --dtype f32 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary 2>"$O/bench_f32.err" | tail -1 | tee "$O/bench_f32_line.json" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('f32 frames/s', d['value'], 'ms', d['ms_per_step'], 'attn frac', d['roofline']['frac'])" ;;
+    rank_probe) (timeout 600 python tools/probes/attn_rank_shape_probe.py 2>&1 | tail -9) | tee "$O/attention_rank_shapes.txt" ;;
+    traffic_only)
+      P=$O/prof_traffic; mkdir -p "$P"
+      (cd /tmp && export TMPDIR=/tmp && i=2 && for set in "FETCH_SIZE TCC_HIT_sum" "WRITE_SIZE TCC_MISS_sum"; do i=$((i + 1)); for v in 8 64; do
+          rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$P/attn_S${v}_pmc$i" -- python "$R/tests/bench_kernels.py" attn --modes global --views $v --variants 0 --rounds 1 --target-ms 60 > "$P/last.log" 2>&1 || { echo "pass FAILED"; tail -5 "$P/last.log"; }
+        done; done)
+      python tools/traffic_json.py --views 8 "$P"/attn_S8_pmc3 "$P"/attn_S8_pmc4 --views 64 "$P"/attn_S64_pmc3 "$P"/attn_S64_pmc4 --out "$O/traffic.json" \
+        --source "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum / WRITE_SIZE TCC_MISS_sum passes (tools/validate_r04.sh traffic_only) of the shipped global-attention launches; PMC counters cannot be read from inside bench.py, so the figure is not re-measured in the bench run" > "$O/traffic_json.log" 2>&1
+      python -c "import json; d=json.load(open('$O/traffic.json')); print('traffic', d['attention_source_digest'][:12], d['global_attn_S64_bytes_per_launch'], d['global_attn_S8_bytes_per_launch'])"
+      find "$P" -name "*.csv" -size +1M -delete ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
