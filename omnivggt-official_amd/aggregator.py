@@ -458,14 +458,20 @@ class ZeroAggregator(nn.Module):
         if len(camera_gt_index) == 0:
             key = ("bias_tables", K)
             if key not in pk:               # Linear(0) = bias for every view; constant across calls
+                cached = [k for k in pk if isinstance(k, tuple) and k and k[0] == "bias_tables"]
+                if len(cached) >= 16:       # same cap as the index cache below: a long-lived process with ever-changing view counts
+                    for k in cached:
+                        del pk[k]
                 pk[key] = ops.camera_tables(None, None, None, K, hw, pk["pose_w"], pk["pose_b"], pk["adapt_w"], pk["adapt_b"])
-            return pk[key]
+            return pk[key]                  # READ-ONLY: the same storage is handed to every forward without cameras (callers only slice it)
         if self.pose_hidden_dim != 9:
             raise ValueError("ovg_camera_tables encodes cameras as absT_quaR_FoV (9 values); pose_hidden_dim=%d" % self.pose_hidden_dim)
         idx_key = ("cam_index", tuple(int(i) for i in camera_gt_index))
         if idx_key not in pk:               # the index list reaches the device once per distinct list, not once per forward
             if min(idx_key[1]) < 0 or max(idx_key[1]) >= S:
                 raise IndexError("camera_gt_index out of range for %d views" % S)
+            if len(set(idx_key[1])) != len(idx_key[1]):
+                raise ValueError("camera_gt_index holds duplicate views (ovg_camera_tables scatters one table row per entry)")
             cached = [k for k in pk if isinstance(k, tuple) and k and k[0] == "cam_index"]
             if len(cached) >= 16:           # a long-lived process with ever-changing index lists: start over
                 for k in cached:

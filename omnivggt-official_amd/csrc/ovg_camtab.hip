@@ -21,6 +21,15 @@ constexpr int ENC = 9;   // absT_quaR_FoV: t(3), quat xyzw(4), fov_h, fov_w  (po
 // rel = [E_r; 0 0 0 1] * inverse([E_0; 0 0 0 1])  with E_0 the FIRST selected camera (omnivggt_aggregator.py:93-97):
 //   R_rel = R_r R_0^T,  t_rel = t_r - R_rel t_0 ... evaluated the way the reference does it: the 4 x 4 product with
 //   inv0 = [R_0^T | -R_0^T t_0] (geometry.py:303-316), so t_rel = R_r (-R_0^T t_0) + t_r.
+// The index array lives on the device and cannot be validated by the host entry: every read through it clamps the view into [0, S)
+// and cam_adapt_kernel skips the scatter of an out-of-range entry (its view keeps the bias row), so a bad index can give a wrong
+// table row but never an out-of-bounds access (the Python front end rejects such lists before they reach the device). Duplicate
+// indices are not supported: two rows would race for one table row (the reference's scatter is last-write-wins).
+OVG_DEV int cam_view(const ovg_camera_tables_params& p, int r) {
+  const int v = p.index[r];
+  return v < 0 ? 0 : (v >= p.S ? p.S - 1 : v);
+}
+
 __global__ __launch_bounds__(256) void cam_encode_kernel(ovg_camera_tables_params p) {
   __shared__ float red[256];
   __shared__ float inv0[12];      // R_0^T (row-major 3 x 3), then -R_0^T t_0
@@ -29,7 +38,7 @@ __global__ __launch_bounds__(256) void cam_encode_kernel(ovg_camera_tables_param
   const float* ext_b = p.extrinsics + (int64_t)b * p.S * 12;
   const float* intr_b = p.intrinsics + (int64_t)b * p.S * 9;
   if (tid == 0) {
-    const float* e0 = ext_b + (int64_t)p.index[0] * 12;
+    const float* e0 = ext_b + (int64_t)cam_view(p, 0) * 12;
     float Rt[9], t0[3] = {e0[3], e0[7], e0[11]};
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) Rt[i * 3 + j] = e0[j * 4 + i];
@@ -39,7 +48,7 @@ __global__ __launch_bounds__(256) void cam_encode_kernel(ovg_camera_tables_param
   __syncthreads();
   // translation of the first selected camera after the change of frame (its own rel): every thread needs it for the distances
   if (tid == 0) {
-    const float* e0 = ext_b + (int64_t)p.index[0] * 12;
+    const float* e0 = ext_b + (int64_t)cam_view(p, 0) * 12;
     for (int i = 0; i < 3; ++i)
       c0[i] = e0[i * 4] * inv0[9] + e0[i * 4 + 1] * inv0[10] + e0[i * 4 + 2] * inv0[11] + e0[i * 4 + 3];
   }
@@ -47,7 +56,7 @@ __global__ __launch_bounds__(256) void cam_encode_kernel(ovg_camera_tables_param
   // pass 1: mean distance of cameras 1 .. Sc-1 to camera 0 (translations of the relative poses, omnivggt_aggregator.py:99-103)
   float dsum = 0.f;
   for (int r = 1 + tid; r < p.Sc; r += 256) {
-    const float* e = ext_b + (int64_t)p.index[r] * 12;
+    const float* e = ext_b + (int64_t)cam_view(p, r) * 12;
     float d2 = 0.f;
     for (int i = 0; i < 3; ++i) {
       const float t = e[i * 4] * inv0[9] + e[i * 4 + 1] * inv0[10] + e[i * 4 + 2] * inv0[11] + e[i * 4 + 3];
@@ -66,7 +75,7 @@ __global__ __launch_bounds__(256) void cam_encode_kernel(ovg_camera_tables_param
   if (p.Sc > 1) scale = fmaxf(red[0] / (float)(p.Sc - 1), 1e-6f);
   // pass 2: the encoding of every selected camera
   for (int r = tid; r < p.Sc; r += 256) {
-    const int view = p.index[r];
+    const int view = cam_view(p, r);
     const float* e = ext_b + (int64_t)view * 12;
     const float* k = intr_b + (int64_t)view * 9;
     float R[9], t[3];
@@ -165,6 +174,7 @@ __global__ __launch_bounds__(64) void cam_adapt_kernel(ovg_camera_tables_params 
     const int r = r0 + rt * 16 + lr;
     if (r < R) {
       const int b = r / p.Sc, view = p.index[r - b * p.Sc];
+      if (view < 0 || view >= p.S) continue;               // out-of-range entry: nothing is scattered
       float* dst = p.tables + ((int64_t)g * K + (int64_t)b * p.S + view) * OVG_C + n0 + 4 * gq;
       *reinterpret_cast<f32x4*>(dst) = acc[rt] + bias;
     }

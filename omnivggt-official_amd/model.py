@@ -35,8 +35,13 @@ except Exception:  # pragma: no cover - optional
 
 class OmniVGGT(nn.Module, _HubMixin):
     def __init__(self, img_size=518, patch_size=14, embed_dim=1024, depth=24, dino_depth=24,
-                 compute_dtype=torch.float32, dpt_layers=(4, 11, 17, 23), hip_heads=True, hip_camera_head=True, hip_heads_f32=True):
+                 compute_dtype=torch.float32, dpt_layers=(4, 11, 17, 23), hip_heads=True, hip_camera_head=True, hip_heads_f32=True,
+                 head_dtype=None):
         super().__init__()
+        # head_dtype: None = the heads follow the aggregator's compute dtype (bf16 / f16 heads in the 16-bit modes, exact-f32 heads in the
+        # f32 and split-f16 modes); torch.float32 = always the exact-f32 HIP heads, i.e. the reference's own arrangement (it disables
+        # autocast around the heads, omnivggt.py:45) at ~5x the heads' time -- README "16-bit heads" has the error table behind the default
+        self.head_dtype = head_dtype
         self.hip_heads = hip_heads
         self.hip_camera_head = hip_camera_head
         self.hip_heads_f32 = hip_heads_f32          # f32 parity mode: all three heads on the HIP f32 kernels (False: PyTorch / MIOpen modules)
@@ -54,7 +59,7 @@ class OmniVGGT(nn.Module, _HubMixin):
         self._hip_cam = HipCameraHead(self.camera_head)
 
     def _camera(self, cam_tokens):
-        dt = L.head_dtype(self.aggregator.compute_dtype)      # split-f16 aggregator: the heads run on the exact-f32 kernels
+        dt = self.head_dtype or L.head_dtype(self.aggregator.compute_dtype)      # split-f16 aggregator: the heads run on the exact-f32 kernels
         toks = cam_tokens[-1]
         lowp = dt in (torch.bfloat16, torch.float16)
         if self.hip_heads and self.hip_camera_head and (lowp or self.hip_heads_f32) and toks.is_cuda and toks.shape[1] <= 4096:
@@ -62,7 +67,7 @@ class OmniVGGT(nn.Module, _HubMixin):
         return self.camera_head(cam_tokens)
 
     def _dpt(self, which, head, tokens, imgs32, patch_start_idx):
-        dt = L.head_dtype(self.aggregator.compute_dtype)
+        dt = self.head_dtype or L.head_dtype(self.aggregator.compute_dtype)
         if self.hip_heads and imgs32.is_cuda and (dt in (torch.bfloat16, torch.float16) or self.hip_heads_f32):
             return self._hip_dpt[which](tokens, imgs32, patch_start_idx, dtype=dt)     # f32: exact-f32 MFMA convolutions (r03)
         return head(tokens, images=imgs32, patch_start_idx=patch_start_idx)

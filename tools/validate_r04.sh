@@ -36,6 +36,7 @@ for stage in "$@"; do
         --source "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum / WRITE_SIZE TCC_MISS_sum passes (tools/validate_r04.sh traffic_only) of the shipped global-attention launches; PMC counters cannot be read from inside bench.py, so the figure is not re-measured in the bench run" > "$O/traffic_json.log" 2>&1
       python -c "import json; d=json.load(open('$O/traffic.json')); print('traffic', d['attention_source_digest'][:12], d['global_attn_S64_bytes_per_launch'], d['global_attn_S8_bytes_per_launch'])"
       find "$P" -name "*.csv" -size +1M -delete ;;
+    attn_ab)    (timeout 900 python tools/probes/attn_ab_probe.py ${OVG_AB_ARGS:-} 2>&1 | grep -v amdgpu.ids | tail -30) | tee "$O/attn_ab.txt" ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
