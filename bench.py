@@ -368,7 +368,7 @@ def main():
         # all_gather_into_tensor calls per layer -- becomes the primary and the report says so.
         wd.stage("pre-flight: both exchange forms, one forward each")
         step = make_step(S)
-        pre = shard.compare_modes(lambda: step()[0][-1], S, args.dtype == "f32", on_stage=wd.stage)
+        pre = shard.compare_modes(lambda: step()[0][-1], S, args.dtype in ("f32", "f32x"), on_stage=wd.stage)
         torch.cuda.synchronize()
         pre["tolerance"] = 5e-2
         pre["agree"] = pre.get("max_rel_heads_vs_allgather", 0.0) <= pre["tolerance"]
@@ -391,7 +391,7 @@ def main():
         first = shard.last_mode
         other = "allgather" if first == "heads" else "heads"
         try:
-            resolve_mode(other, S, world, args.dtype == "f32")       # same answer on every rank, no communication
+            resolve_mode(other, S, world, args.dtype in ("f32", "f32x"))       # same answer on every rank, no communication
             possible = result.get("preflight", {}).get("agree", True) or other == "allgather"
         except ValueError:
             possible = False
@@ -440,6 +440,7 @@ def main():
             # 16-bit modes the DPT heads run on the HIP kernels (heads_hip.py), `--torch-heads` forces PyTorch's
             try:
                 Se = args.e2e_views
+                hd = "f32" if args.dtype in ("f32", "f32x") else args.dtype       # the split-f16 aggregator keeps the heads on the exact-f32 kernels
                 inp = synthetic_inputs(Se, dev, aux=args.aux)
                 idx = list(range(Se)) if args.aux else []
                 model.hip_heads = not args.torch_heads
@@ -453,8 +454,8 @@ def main():
                 torch.cuda.synchronize()
                 ms = (time.perf_counter() - t1) / 3 * 1e3
                 result["e2e"] = {"views": Se, "frames_per_s": round(Se / ms * 1e3, 3), "ms_per_forward": round(ms, 3),
-                                 "dpt_heads": "pytorch-f32" if (args.torch_heads or (args.dtype == "f32" and not model.hip_heads_f32)) else "hip-" + args.dtype,
-                                 "camera_head": "pytorch-f32" if (args.torch_heads or (args.dtype == "f32" and not model.hip_heads_f32)) else "hip-" + args.dtype}
+                                 "dpt_heads": "pytorch-f32" if (args.torch_heads or (hd == "f32" and not model.hip_heads_f32)) else "hip-" + hd,
+                                 "camera_head": "pytorch-f32" if (args.torch_heads or (hd == "f32" and not model.hip_heads_f32)) else "hip-" + hd}
             except Exception as e:  # never let the heads hide the hot-path number
                 result["e2e_error"] = repr(e)[:200]
         if not args.no_cpu_baseline:

@@ -44,7 +44,8 @@ extern "C" {
  *    entries, ovg_attn_plan_out.main_rows / tail_q_tile (the tail split of long attention launches is part of the queryable plan)
  * 8: OVG_F16X2 -- the split-f16 compute mode ("f32x": every 16-bit operand tensor is a PAIR of f16 planes hi + lo, products run as
  *    three f16 MFMAs hi*hi + hi*lo + lo*hi with f32 accumulation: ~2^-22 per product instead of 2^-8 (bf16) / 2^-11 (f16) at
- *    a third of the 16-bit MFMA rate; the `*_lo` pointers below, NULL / ignored for the other dtypes);
+ *    a third of the 16-bit MFMA rate; the `*_lo` pointers below, NULL / ignored for the other dtypes; single GPU and the K / V^T
+ *    all-gather sharded form incl. ovg_attn_merge);
  *    ovg_attn_params.fallback_count / ovg_block_params.attn_fallback_count (telemetry of the speculative bf16 softmax) */
 #define OVG_ABI_VERSION 8
 
@@ -229,6 +230,7 @@ typedef struct {
   const void* b; int64_t ldb; const float* lse_b;
   void* out; int64_t ldo;
   int64_t rows; int64_t n_pad; int dtype;
+  const void* a_lo; const void* b_lo; void* out_lo;   /* OVG_F16X2: lo planes of a / b / out (same strides) */
 } ovg_attn_merge_params;
 int ovg_attn_merge(const ovg_attn_merge_params*, void* stream);
 

@@ -538,8 +538,6 @@ class ZeroAggregator(nn.Module):
         if not images.is_cuda:
             raise L.OvgError("ZeroAggregator.forward needs HIP device tensors: there is no CPU fallback")
         if self.shard is not None:
-            if L.is_split(self.compute_dtype):
-                raise L.OvgError("the split-f16 mode (f32x) is single-GPU: the view-sharded exchange forms move one 16-bit plane per tensor")
             return self.shard.forward(self, images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index)
         device = images.device
         pk = self.pack(device)

@@ -384,11 +384,7 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
 #define PB_MFMA_NEW(d, a, b, c) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c))
 #define PB_MFMA_ACC(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 #define PB_SPLIT(kt, qb) do { s[kt][qb][0] = t[kt][qb][0]; s[kt][qb][1] = t[kt][qb][1]; s[kt][qb][2] = t[kt][qb][2]; s[kt][qb][3] = t[kt][qb][3]; } while (0)
-#ifdef OVG_ATTN_PIPE_PACKNOP   // A/B: a wait-state statement that OWNS the packed fragment, so a compiler-made copy cannot sit next to the consuming MFMA
-#define PB_PACK(u, qb) do { pf[u][qb] = u32x4{pw[u][qb][0], pw[u][qb][1], pw[u][qb][2], pw[u][qb][3]}; asm volatile("s_nop 1" : "+v"(pf[u][qb])); } while (0)
-#else
 #define PB_PACK(u, qb) pf[u][qb] = u32x4{pw[u][qb][0], pw[u][qb][1], pw[u][qb][2], pw[u][qb][3]}
-#endif
   constexpr bool PIPE = SM == 2 && (QB == 4 || QB == 2) && DMA > 0 && !VSUM && std::is_same<T, bf16_t>::value;
   auto pipe_tile = [&](int slot) {
     if constexpr (PIPE) {
@@ -485,13 +481,16 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
     }
   };
   int j_all = 0;
-  // OVG_ATTN_PIPE_LOOP (A/B builds, tools/probes/build_alt.py): 0 = no pinned body; 1 (shipped) = the leading full tiles of a
-  // single-segment launch; 2 = every full tile of every segment (pinned loop + one compiler-scheduled masked tile per segment inside
-  // an outer loop). FORM 2 IS NOT SHIPPED: with it hipcc (ROCm 7.2) no longer coalesces the PB_PACK copies -- it materialises
-  // pf = {pw...} as v_mov_b64 pairs directly in front of the consuming asm MFMA, inside the VALU-write -> MFMA-read hazard window the
-  // generator guarantees only for its own v_cvt_pk statements; the MFMA reads stale P, the pass produces garbage, EVERY workgroup fails
-  // its verification and re-runs (r04: 688 of 688 fallback workgroups, 2.1x slower, results still exact: profiles/r04_attn_ab_loop_forms.txt).
-  // tests/test_attn_body_generator.py::test_pinned_hot_loops_hold_no_compiler_copies disassembles the shipped kernels and fails on such a copy.
+  // OVG_ATTN_PIPE_LOOP (A/B builds, tools/probes/build_alt.py): 1 (shipped) = the pinned body on the leading full tiles of a
+  // single-segment launch, 0 = compiler-scheduled body everywhere.
+  // Measured and NOT shipped (r04, profiles/r04_attn_ab_loop_forms.txt): the pinned loop for every full tile of every segment (pinned
+  // loop + one compiler-scheduled masked tile per segment inside an outer loop, for the multi-segment launches of the view-sharded run).
+  // Bit-wrong speculative pass: with that control flow hipcc (ROCm 7.2) stops coalescing the PB_PACK copies -- v_mov_b64 pairs appear
+  // directly in front of the consuming asm MFMA, inside the VALU-write -> MFMA-read hazard window the generator guarantees only for its
+  // own statements -- and a build with wait states owned by the packed fragment failed the same way, so there is at least one more
+  // ordering assumption that only holds for the straight-line form. EVERY workgroup failed its verification and re-ran (688 of 688
+  // fallback workgroups, 2.1x slower, results still exact) -- found by the fallback counter, invisible to every parity test.
+  // tests/test_attn_body_generator.py::test_pinned_hot_loops_hold_no_compiler_copies guards the shipped kernels against such copies.
 #ifndef OVG_ATTN_PIPE_LOOP
 #define OVG_ATTN_PIPE_LOOP 1
 #endif
@@ -502,19 +501,6 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
     n_full = n_full < total_tiles ? n_full : total_tiles;
     for (; j_all < n_full; ++j_all) tile_iter(j_all, std::true_type{});
     asm volatile("s_nop 15\n\ts_nop 15");     // asm MFMA results -> VALU / builtin readers behind the loop (hipcc does not see the hazard)
-  }
-#elif OVG_ATTN_PIPE_LOOP == 2
-  if constexpr (PIPE) {
-    // Segment by segment (one segment on a single GPU; one per rank / source after a view-sharded exchange): the FULL tiles of the
-    // segment in a loop of the pinned body -- tile t of a segment is full iff (t + 1) * BC <= nk -- then its masked last tile, if
-    // any, through the compiler-scheduled body (a single call per segment, outside the hot loop).
-    while (j_all < total_tiles) {
-      int n_full = c_nk / BC - ctile;
-      n_full = n_full < total_tiles - j_all ? n_full : total_tiles - j_all;
-      for (int i = 0; i < n_full; ++i, ++j_all) tile_iter(j_all, std::true_type{});
-      asm volatile("s_nop 15\n\ts_nop 15");   // asm MFMA results -> VALU / builtin readers behind the loop (hipcc does not see the hazard)
-      if (j_all < total_tiles && (ctile + 1) * BC > c_nk) { tile_iter(j_all, std::false_type{}); ++j_all; }   // the current tile is a masked one (else: the segment ended on a full tile and the cursor is already in the next segment)
-    }
   }
 #endif
   for (; j_all < total_tiles; ++j_all) tile_iter(j_all, std::false_type{});

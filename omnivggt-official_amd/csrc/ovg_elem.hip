@@ -236,7 +236,7 @@ extern "C" int ovg_heads_to_tokens(const ovg_heads_to_tokens_params* p, void* st
 
 // Exact combination of two attention results over disjoint key sets (header: ovg_attn_merge). One thread = 4
 // consecutive d of one (token, head); lse is head-major [16, n_pad] as written by the attention kernels.
-template <typename T>
+template <typename T, bool X3 = false>   // X3 (OVG_F16X2): a, b, out are (hi, lo) f16 plane pairs
 __global__ __launch_bounds__(256) void attn_merge_kernel(ovg_attn_merge_params p, int64_t total) {
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     const int c = (int)(idx & 255);                     // 4-element chunk of the 1024-wide row
@@ -249,6 +249,15 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(ovg_attn_merge_params p
     const T* a = static_cast<const T*>(p.a) + row * p.lda + c * 4;
     const T* b = static_cast<const T*>(p.b) + row * p.ldb + c * 4;
     float r[4];
+    if constexpr (X3) {
+      const f16_t* al = static_cast<const f16_t*>(p.a_lo) + row * p.lda + c * 4;
+      const f16_t* bl = static_cast<const f16_t*>(p.b_lo) + row * p.ldb + c * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        r[i] = (wa * (static_cast<float>(a[i]) + static_cast<float>(al[i])) + wb * (static_cast<float>(b[i]) + static_cast<float>(bl[i]))) * inv;
+      store4_hilo(static_cast<f16_t*>(p.out) + row * p.ldo + c * 4, static_cast<f16_t*>(p.out_lo) + row * p.ldo + c * 4, r[0], r[1], r[2], r[3]);
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) r[i] = (wa * TT<T>::to_f32(a[i]) + wb * TT<T>::to_f32(b[i])) * inv;
     store4<T>(static_cast<T*>(p.out) + row * p.ldo + c * 4, r[0], r[1], r[2], r[3]);
@@ -266,6 +275,9 @@ extern "C" int ovg_attn_merge(const ovg_attn_merge_params* p, void* stream) {
     case OVG_BF16: OVG_LAUNCH((attn_merge_kernel<bf16_t>), grid, block, 0, st, *p, total); break;
     case OVG_F16: OVG_LAUNCH((attn_merge_kernel<f16_t>), grid, block, 0, st, *p, total); break;
     case OVG_F32: OVG_LAUNCH((attn_merge_kernel<float>), grid, block, 0, st, *p, total); break;
+    case OVG_F16X2:
+      if (!p->a_lo || !p->b_lo || !p->out_lo || !al16(p->a_lo) || !al16(p->b_lo) || !al16(p->out_lo)) return OVG_E_ARG;
+      OVG_LAUNCH((attn_merge_kernel<f16_t, true>), grid, block, 0, st, *p, total); break;
     default: return OVG_E_DTYPE;
   }
   OVG_CHECK_LAUNCH();

@@ -62,7 +62,7 @@ class AttnPlanOut(C.Structure):
 
 class AttnMergeParams(C.Structure):
     _fields_ = [("a", vp), ("lda", i64), ("lse_a", vp), ("b", vp), ("ldb", i64), ("lse_b", vp),
-                ("out", vp), ("ldo", i64), ("rows", i64), ("n_pad", i64), ("dtype", i32)]
+                ("out", vp), ("ldo", i64), ("rows", i64), ("n_pad", i64), ("dtype", i32), ("a_lo", vp), ("b_lo", vp), ("out_lo", vp)]
 
 
 class BlockWeights(C.Structure):

@@ -243,13 +243,15 @@ def flash_attn(q, segments, nq, dtype, out=None, variant=0, kv_heads=0, head_maj
 def attn_merge(a, lse_a, b, lse_b, dtype, out=None):
     """Exact merge of two token-major attention results [n, 1024] over disjoint key sets (B = 1);
     lse_a / lse_b f32 [16, n_pad] from flash_attn(..., lse=...). out may alias a or b."""
-    _chk_dev(a, b, lse_a, lse_b, out)
     if out is None:
-        out = torch.empty_like(a)
+        out = empty_like_dtype(tuple(a.shape), dtype, a.device)
+    ret = out
+    (a, a_lo), (b, b_lo), (out, out_lo) = hi_lo(a), hi_lo(b), hi_lo(out)
+    _chk_dev(a, b, lse_a, lse_b, out)
     p = L.AttnMergeParams(L.ptr(a), a.stride(0), L.ptr(lse_a), L.ptr(b), b.stride(0), L.ptr(lse_b), L.ptr(out), out.stride(0),
-                          a.shape[0], lse_a.shape[1], L.dtype_code(dtype))
+                          a.shape[0], lse_a.shape[1], L.dtype_code(dtype), L.ptr(a_lo), L.ptr(b_lo), L.ptr(out_lo))
     L.call("ovg_attn_merge", p, _stream())
-    return out
+    return ret
 
 
 def pack_weights(src, dtype, k_pad=None):

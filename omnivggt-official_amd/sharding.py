@@ -59,7 +59,8 @@ def partition(n_views, world):
 
 def resolve_mode(requested, n_views, world, is_f32):
     """Exchange form for this call; deterministic in its arguments (all ranks compute the same answer).
-    Raises ValueError for an explicit request the shapes / dtype cannot run."""
+    Raises ValueError for an explicit request the shapes / dtype cannot run. is_f32: the compute mode is one of the <= 1e-4 modes
+    (f32 or split-f16) -- those shard through the K / V^T all-gather form only."""
     eligible = n_views % world == 0 and 16 % world == 0 and not is_f32
     if requested == "heads":
         if not eligible:
@@ -69,6 +70,12 @@ def resolve_mode(requested, n_views, world, is_f32):
     if requested == "allgather":
         return "allgather"
     return "heads" if (eligible and world > 1) else "allgather"
+
+
+def _parity_mode(agg):
+    """True for the <= 1e-4 compute modes (f32, split-f16): they shard through the K / V^T all-gather form only."""
+    dt = getattr(agg, "compute_dtype", None)
+    return dt is torch.float32 or ops.L.is_split(dt)
 
 
 def head_groups(heads_per_rank, world=1, n_tokens=None):
@@ -125,16 +132,26 @@ class HipExecutor:
             ws_f = self.agg.workspace(n_local * P, P, self.device)
             pad = ops.pad_to(max_local * P, ops.KV_TILE)
             ws_g = Workspace(n_local * P, n_local * P, dt, self.device, share=ws_f, kv_rows=pad)
-            ws_g.o_b = torch.empty(n_local * P, C, device=self.device, dtype=dt)
+            ws_g.o_b = ops.empty_like_dtype((n_local * P, C), dt, self.device)      # split-f16 mode: an ops.HiLo pair like ws.attn
             ws_g.lse_a = torch.empty(16, pad, device=self.device, dtype=torch.float32)
             ws_g.lse_b = torch.empty(16, pad, device=self.device, dtype=torch.float32)
             return ws_f, ws_g
         return self._cached(("ag", n_local, max_local, P), make)
 
+    @staticmethod
+    def _wire(t):
+        """The tensor that goes on the wire for a K / V^T buffer: the buffer itself, or both planes of a split-f16 pair [2, ...]."""
+        return t.planes if isinstance(t, ops.HiLo) else t
+
+    @staticmethod
+    def _unwire(t, like):
+        return ops.HiLo(t) if isinstance(like, ops.HiLo) else t
+
     def gather_buffers(self, ws_g, world):
-        return self._cached(("agbuf", tuple(ws_g.k.shape), world), lambda: (
-            torch.empty((world,) + tuple(ws_g.k.shape), device=self.device, dtype=ws_g.k.dtype),
-            torch.empty((world,) + tuple(ws_g.vt.shape), device=self.device, dtype=ws_g.vt.dtype)))
+        k, vt = self._wire(ws_g.k), self._wire(ws_g.vt)
+        return self._cached(("agbuf", tuple(k.shape), world), lambda: (
+            torch.empty((world,) + tuple(k.shape), device=self.device, dtype=k.dtype),
+            torch.empty((world,) + tuple(vt.shape), device=self.device, dtype=vt.dtype)))
 
     def frame_block(self, i, ws, x_in, x_out, inject, P):
         self.pk["frame"][i].forward(ws, x_in, x_out, inject=inject, inj_period=P, **self._geo())
@@ -147,7 +164,7 @@ class HipExecutor:
 
     def global_kv(self, i, ws, x_in, x_out):
         self._prologue(i, ws, x_in, x_out, 1)
-        return ws.k, ws.vt
+        return self._wire(ws.k), self._wire(ws.vt)
 
     def global_q(self, i, ws, x_in, x_out):
         self._prologue(i, ws, x_in, x_out, 2)
@@ -158,7 +175,7 @@ class HipExecutor:
         dt, variant = self.agg.compute_dtype, self.agg.attn_variant
         splits = getattr(self.agg, "attn_kv_splits", 0)
         split_ws = None
-        if splits != 1 and dt != torch.float32:     # per-rank launches are the ones that quantise badly (688 workgroups on 512 slots)
+        if splits != 1 and dt in (torch.bfloat16, torch.float16):     # per-rank launches are the ones that quantise badly (688 workgroups on 512 slots)
             key = ("split", q.shape[0], n, q.shape[1], tuple(s[2] for s in segs), variant, splits)
             split_ws = self._cached(key, lambda: ops.alloc_split_ws(
                 ops.attn_plan(q.shape[0], n, [s[2] for s in segs], dt, variant, splits, nq_pad=q.shape[1]), self.device))
@@ -177,7 +194,7 @@ class HipExecutor:
 
     def attend_remote(self, i, ws, kg, vg, counts, rank, n):
         """Launch B: the same queries against the gathered segments of the other ranks -> ws.o_b, lse_b."""
-        segs = [(kg[r], vg[r], c) for r, c in enumerate(counts) if r != rank]
+        segs = [(self._unwire(kg[r], ws.k), self._unwire(vg[r], ws.vt), c) for r, c in enumerate(counts) if r != rank]
         self._attention(ws.q, segs, n, ws.o_b, lse=ws.lse_b)
 
     def merge_finish(self, i, ws, x_in, x_out, n, merged):
@@ -344,7 +361,7 @@ class ViewSharding:
         if self.world > ops.L.OVG_MAX_SEG:
             raise ValueError("at most %d ranks per attention call" % ops.L.OVG_MAX_SEG)
         # every check that can fail happens here, identically on every rank, BEFORE the first collective
-        mode = resolve_mode(self.mode, S, self.world, getattr(agg, "compute_dtype", None) == torch.float32)
+        mode = resolve_mode(self.mode, S, self.world, _parity_mode(agg))
         self.last_mode = mode
         agg.set_geometry(images.shape[-2], images.shape[-1])
         P = agg.tokens_per_view
@@ -426,7 +443,7 @@ class ViewSharding:
     def exchange_only(self, agg, S, device, mode=None, layers=24):
         """bench.py: issue ONLY the collectives of `layers` global blocks (same sizes, same order, nothing to hide
         behind) on the cached buffers -- the un-overlapped cost of the exchange."""
-        mode = resolve_mode(mode or self.mode, S, self.world, getattr(agg, "compute_dtype", None) == torch.float32)
+        mode = resolve_mode(mode or self.mode, S, self.world, _parity_mode(agg))
         P = agg.tokens_per_view
         parts = partition(S, self.world)
         lo, hi = parts[self.rank]
@@ -450,8 +467,8 @@ class ViewSharding:
             _, ws_g = ex.workspaces(hi - lo, max(h - l for l, h in parts), P)
             kg, vg = ex.gather_buffers(ws_g, W)
             for _ in range(layers):
-                wk = self._all_gather(kg.flatten(0, 1), ws_g.k, async_op=True)
-                wv = self._all_gather(vg.flatten(0, 1), ws_g.vt, async_op=True)
+                wk = self._all_gather(kg.flatten(0, 1), ex._wire(ws_g.k), async_op=True)
+                wv = self._all_gather(vg.flatten(0, 1), ex._wire(ws_g.vt), async_op=True)
                 wk.wait()
                 wv.wait()
         return mode

@@ -278,6 +278,45 @@ def test_attn(quick):
 
 
 
+def test_attn_fallback_counter():
+    """Speculative-softmax telemetry (ovg_attn_params.fallback_count, round-3 review): global attention at the 8-view key count with
+    ATTENTION-SINK logits -- every query carries a common component, a few keys answer it with +40 ... +130 log2 units -- inside and
+    outside the first key tile (the tile the speculative pass anchors on). The result must be the exact softmax in every case (float64
+    reference on sampled rows); the counter must stay 0 while the sinks fit the f32 exponent window of the anchored pass (|log2| <= 100
+    around the first-tile maximum) and must report every workgroup once the window is left."""
+    g = torch.Generator().manual_seed(77)
+    dt, BH, n = torch.bfloat16, 16, 8 * 1374
+    rows = torch.tensor([0, 1, 17, 255, 256, 4000, 8191, n - 300, n - 1])
+    # logits without sinks: ~N(0, 9.5) log2 units, first-tile maxima 10 ... 30; a sink adds 4 * gain to every query's logit
+    cases = (("none", [], 0.0, 0), ("first_tile_+88", [5], 22.0, 0), ("late_+40", [3000, 9000], 10.0, 0), ("late_+56", [7777], 14.0, 0),
+             ("late_+130", [7777], 32.5, None))                        # None: every workgroup must have re-run
+    q32 = torch.randn(BH, n, 64, generator=g) * 1.2
+    q32[:, :, 0] = 4.0                                                 # the common component every sink key answers
+    k32 = torch.randn(BH, n, 64, generator=g)
+    k32[:, :, 0] = 0.0
+    v32 = torch.randn(BH, n, 64, generator=g)
+    cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for name, sinks, gain, want in cases:
+        kk = k32.clone()
+        for idx in sinks:
+            kk[:, idx, 0] = gain                                       # logit boost 4 * gain log2 units for every query
+        q, k, v = q32.to(dt), kk.to(dt), v32.to(dt)
+        qd, kd, vtd = ops.alloc_qkv(BH, n, n, dt, DEV)
+        qd[:, :n], kd[:, :n] = q.to(DEV), k.to(DEV)
+        ops.set_vt(vtd, v.transpose(1, 2))
+        cnt.zero_()
+        out = ops.flash_attn(qd, [(kd, vtd, n)], n, dt, fallback_count=cnt)
+        torch.cuda.synchronize()
+        ref = attn_reference(q[:, rows].double(), k.double(), v.double()).permute(1, 0, 2).reshape(len(rows), 1024)
+        report("attn_fallback_%s" % name, out[rows.to(DEV)], ref, TOL["bf16"])
+        got = int(cnt.item())
+        plan = ops.attn_plan(BH, n, [n], dt)
+        wgs = BH * ((n + plan["q_tile"] - 1) // plan["q_tile"])
+        ok = (got == want) if want is not None else (got == wgs)
+        print("[%s] attn_fallback_%s: %d of %d workgroups re-ran (expected %s)" % ("PASS" if ok else "FAIL", name, got, wgs, "all" if want is None else want), flush=True)
+        results.append({"name": "attn_fallback_%s.count" % name, "ok": bool(ok), "rel": float(got)})
+
+
 def test_f32x(quick):
     """The split-f16 mode (OVG_F16X2, L.F32X): every 16-bit tensor is a (hi, lo) pair of f16 planes and every contraction three f16
     MFMAs. Inputs are PLAIN f32 values (split by the library's own rounding rule, ops.to_hilo / ovg_pack_weights); the references are
@@ -968,7 +1007,7 @@ def main():
     tests = {"probe": test_probe, "layernorm": test_layernorm, "linear": lambda: test_linear(args.quick), "qkv": lambda: test_qkv(args.quick),
              "attn": lambda: test_attn(args.quick), "embed": test_embed, "block": lambda: test_block(args.quick),
              "heads": lambda: test_heads(args.quick), "gemm256": lambda: test_gemm256(args.quick), "attn_big": lambda: test_attn_big(args.quick),
-             "lse_merge": test_attn_lse_merge, "camera": lambda: test_camera_head(timing=True), "f32x": lambda: test_f32x(args.quick)}
+             "lse_merge": test_attn_lse_merge, "camera": lambda: test_camera_head(timing=True), "f32x": lambda: test_f32x(args.quick), "fallback": test_attn_fallback_counter}
     for name, fn in tests.items():
         if args.only and name not in args.only.split(","):
             continue

@@ -90,6 +90,13 @@ def test_attention_lse_output_and_merge_and_weight_pack():
     _assert_clean()
 
 
+def test_speculative_softmax_fallback_counter_with_attention_sinks():
+    """fallback_count telemetry: exact results with attention-sink logits, 0 re-runs inside the anchored pass's exponent window,
+    every workgroup reported beyond it."""
+    st.test_attn_fallback_counter()
+    _assert_clean()
+
+
 def test_split_f16_mode_kernels_vs_float64():
     """OVG_F16X2 ("f32x", the <= 1e-4 mode with throughput): pack / LayerNorm / im2col splits, every GEMM epilogue on both tile sizes,
     the fused QKV epilogue and the three-MFMA flash attention (segments, ragged tails, forced rescale, log-sum-exp), each within 1e-5

@@ -315,11 +315,12 @@ def test_eight_ranks_head_parallel_emulated_match_monolithic(S, dgi, cgi):
     print("8 emulated ranks, head-parallel, S=%d (plan: %d-row q tiles, split-KV x%d): max-rel vs monolithic %.2e" % (S, plan["q_tile"], plan["splits"], worst))
 
 
-@pytest.mark.parametrize("S,dtype,tol", [(20, torch.bfloat16, 2e-2), (20, torch.float32, 1e-5), (64, torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("S,dtype,tol", [(20, torch.bfloat16, 2e-2), (20, torch.float32, 1e-5), (20, L.F32X, 1e-5), (64, torch.bfloat16, 2e-2)])
 def test_eight_ranks_allgather_emulated_match_monolithic(S, dtype, tol):
     """8 ranks, K / V^T all-gather form (the north star's collective). S = 20 shards unevenly (3/3/3/3/2/2/2/2): the 2-view
     ranks' buffers are padded to 3 views and their segments carry nk = 2 * 1374; launch B walks 7 remote segments. S = 64 is
-    the scaling bench's per-rank shape in this form. f32 = the parity mode's sharded path."""
+    the scaling bench's per-rank shape in this form. f32 = the parity mode's sharded path; lib.F32X = the split-f16 mode's (both planes
+    of K / V^T travel as one [2, ...] tensor, launches A and B write (hi, lo) pairs, ovg_attn_merge combines them in f32)."""
     L.require_gpu()
     m = build(1, 1, dtype)
     agg = m.aggregator
@@ -334,4 +335,4 @@ def test_eight_ranks_allgather_emulated_match_monolithic(S, dtype, tol):
         assert [h - l for l, h in parts] == [3, 3, 3, 3, 2, 2, 2, 2]
     ranks = _emulate_allgather(agg, inputs, parts, agg.tokens_per_view)
     worst = _stitched_vs_monolithic(agg, ranks, ref, tol)
-    print("8 emulated ranks, K/V all-gather, S=%d %s: max-rel vs monolithic %.2e" % (S, str(dtype).replace("torch.", ""), worst))
+    print("8 emulated ranks, K/V all-gather, S=%d %s: max-rel vs monolithic %.2e" % (S, repr(dtype).replace("torch.", ""), worst))

@@ -37,6 +37,14 @@ for stage in "$@"; do
       python -c "import json; d=json.load(open('$O/traffic.json')); print('traffic', d['attention_source_digest'][:12], d['global_attn_S64_bytes_per_launch'], d['global_attn_S8_bytes_per_launch'])"
       find "$P" -name "*.csv" -size +1M -delete ;;
     attn_ab)    (timeout 900 python tools/probes/attn_ab_probe.py ${OVG_AB_ARGS:-} 2>&1 | grep -v amdgpu.ids | tail -30) | tee "$O/attn_ab.txt" ;;
+    configs)    # the other BASELINE configs + end-to-end lines (aggregator + three heads), one JSON line each
+      run() { name=$1; shift; timeout 900 python bench.py "$@" --no-cpu-baseline 2>"$O/$name.err" | tail -1 > "$O/$name.json"; python -c "import sys,json; d=json.load(open('$O/$name.json')); print('$name', d['value'], 'frames/s', d['ms_per_step'], 'ms', 'frac', d['roofline']['frac'], 'e2e', d.get('e2e'), 'parity', {k: max(v['max_rel']) for k, v in d.get('parity', {}).items() if isinstance(v, dict) and 'max_rel' in v})" || tail -5 "$O/$name.err"; }
+      run bench_config2_S16_aux --views 16 --aux --steps 10 --warmup 2
+      run bench_config4_S128_f16_partial_aux --views 128 --dtype f16 --partial-aux --steps 3 --warmup 1
+      run bench_e2e_S8 --views 8 --steps 10 --warmup 2 --no-parity --e2e --e2e-views 8
+      run bench_e2e_S64 --views 64 --steps 4 --warmup 1 --no-parity --e2e --e2e-views 64
+      run bench_f32x_e2e_S8 --dtype f32x --views 8 --steps 5 --warmup 1 --no-parity --e2e --e2e-views 8
+      run bench_f32_S64 --dtype f32 --views 64 --steps 2 --warmup 1 --no-parity ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
