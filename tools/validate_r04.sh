@@ -45,6 +45,8 @@ for stage in "$@"; do
       run bench_e2e_S64 --views 64 --steps 4 --warmup 1 --no-parity --e2e --e2e-views 64
       run bench_f32x_e2e_S8 --dtype f32x --views 8 --steps 5 --warmup 1 --no-parity --e2e --e2e-views 8
       run bench_f32_S64 --dtype f32 --views 64 --steps 2 --warmup 1 --no-parity ;;
+    printed)    (timeout 1500 python -m pytest tests/test_gpu_aggregator.py tests/test_gpu_sharded.py tests/test_gpu_kernels.py -m gpu -q -s \
+                   -k "full_depth_8_views or attention_sinks or eight_ranks_allgather or headline_64 or stress_128" 2>&1 | grep -E "vs oracle|re-ran|emulated ranks|passed|failed|Error" | cut -c1-400) | tee "$O/printed_parity_numbers.txt" ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
