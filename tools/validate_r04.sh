@@ -47,6 +47,8 @@ for stage in "$@"; do
       run bench_f32_S64 --dtype f32 --views 64 --steps 2 --warmup 1 --no-parity ;;
     printed)    (timeout 1500 python -m pytest tests/test_gpu_aggregator.py tests/test_gpu_sharded.py tests/test_gpu_kernels.py -m gpu -q -s \
                    -k "full_depth_8_views or attention_sinks or eight_ranks_allgather or headline_64 or stress_128" 2>&1 | grep -E "vs oracle|re-ran|emulated ranks|passed|failed|Error" | cut -c1-400) | tee "$O/printed_parity_numbers.txt" ;;
+    multirank_f32x) OVG_MULTIRANK_CFGS="2:8" OVG_MULTIRANK_ARGS="--dtype f32x --no-second-form" bash tools/multirank_one_gpu.sh 2>&1 | tee "$O/multirank_one_gpu_gloo_f32x.txt" ;;
+    heads_dtype) (timeout 900 python tools/probes/heads_dtype_probe.py 2>&1 | grep -v amdgpu.ids | tail -20) | tee "$O/heads_dtype_probe.txt" ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
