@@ -183,7 +183,7 @@ class HipExecutor:
         if ev is not None:
             ev[0].record()
         ops.flash_attn(q, segs, n, dt, out=out, variant=variant, kv_heads=kv_heads, head_major=head_major, lse=lse,
-                       kv_splits=splits, split_ws=split_ws)
+                       kv_splits=splits, split_ws=split_ws, fallback_count=getattr(self.agg, "fallback_counter", None))
         if ev is not None:
             ev[1].record()
         return out

@@ -49,6 +49,33 @@ for stage in "$@"; do
                    -k "full_depth_8_views or attention_sinks or eight_ranks_allgather or headline_64 or stress_128" 2>&1 | grep -E "vs oracle|re-ran|emulated ranks|passed|failed|Error" | cut -c1-400) | tee "$O/printed_parity_numbers.txt" ;;
     multirank_f32x) OVG_MULTIRANK_CFGS="2:8" OVG_MULTIRANK_ARGS="--dtype f32x --no-second-form" bash tools/multirank_one_gpu.sh 2>&1 | tee "$O/multirank_one_gpu_gloo_f32x.txt" ;;
     heads_dtype) (timeout 900 python tools/probes/heads_dtype_probe.py 2>&1 | grep -v amdgpu.ids | tail -20) | tee "$O/heads_dtype_probe.txt" ;;
+    pmc)        # SQ / GRBM counter passes (own runs, only --kernel-trace next to --pmc): shipped bf16 attention and GEMM launches, split-f16 forward
+      P=$O/prof_pmc; mkdir -p "$P"
+      (cd /tmp && export TMPDIR=/tmp
+       run() { "$@" > "$P/last.log" 2>&1 || { echo "   FAILED: $*"; tail -4 "$P/last.log"; }; }
+       i=0
+       for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+                  "SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE"; do
+         i=$((i + 1))
+         for v in 8 64; do
+           run rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$P/attn_S${v}_pmc$i" -- python "$R/tests/bench_kernels.py" attn --modes global --views $v --variants 0 --rounds 1 --target-ms 60
+           run rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$P/gemm_S${v}_pmc$i" -- python "$R/tests/bench_kernels.py" gemm --views $v --tiles 0 --rounds 1 --target-ms 5
+           run rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$P/f32x_S${v}_pmc$i" -- python "$R/bench.py" --dtype f32x --views $v --steps 1 --warmup 1 --no-cpu-baseline --no-parity --no-secondary
+         done
+       done)
+      python tools/pmc_summary.py "$P"/attn_S* > "$O/pmc_attention.txt" 2>&1
+      python tools/pmc_summary.py "$P"/gemm_S64_* > "$O/pmc_gemm.txt" 2>&1
+      python tools/pmc_summary.py "$P"/gemm_S8_* > "$O/pmc_gemm_S8.txt" 2>&1
+      python tools/pmc_summary.py "$P"/f32x_S64_* --only attn16_kernel --only linear --only qkv > "$O/pmc_f32x_S64.txt" 2>&1
+      python tools/pmc_summary.py "$P"/f32x_S8_* --only attn16_kernel --only linear --only qkv > "$O/pmc_f32x_S8.txt" 2>&1
+      grep -h "grid=\|matrix pipe\|effective clock" "$O/pmc_attention.txt" "$O/pmc_f32x_S64.txt" | cut -c1-170 | head -40
+      find "$P" -name "*.csv" -size +1M -delete ;;
+    prof_f32x)  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_f32x_S64" -- python "$R/bench.py" --dtype f32x --views 64 --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-secondary > "$O/prof_f32x_S64.log" 2>&1)
+      f=$(find "$O/prof_f32x_S64" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$O/bench_f32x_S64_kernel_stats.csv" && head -9 "$f" | cut -c1-200
+      find "$O/prof_f32x_S64" -name "*.csv" -size +1M -delete ;;
+    sweep)      for v in 4 12 16 24 32 48; do
+        timeout 600 python bench.py --views $v --steps 6 --warmup 2 --no-cpu-baseline --no-parity 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('views', d['config']['views'], 'frames/s', d['value'], 'ms', d['ms_per_step'], 'attention ms', d['roofline']['avg_launch_ms'], 'frac', d['roofline']['frac'], 'fallback', d['roofline']['fallback_workgroups'])"
+      done 2>&1 | tee "$O/bench_view_sweep.txt" ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
