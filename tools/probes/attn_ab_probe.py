@@ -85,7 +85,8 @@ def main():
             base = statistics.median(times["product"])
             for nm in libs:
                 ms = statistics.median(times[nm])
-                same = bool(torch.equal(outs[nm].view(torch.int16), outs["product"].view(torch.int16)))
+                valid = (lambda t: t[:, :n]) if head_major else (lambda t: t)      # head-major outputs carry uninitialised padding rows
+                same = bool(torch.equal(valid(outs[nm]).contiguous().view(torch.int16), valid(outs["product"]).contiguous().view(torch.int16)))
                 print("%-6s variant %-2d %-8s median %8.4f ms  %7.1f TFLOP/s  vs product %+6.2f%%  fallback workgroups %d  bits==product %s  (q tile %d)"
                       % (shape, v, nm, ms, flop / ms / 1e9, (base / ms - 1) * 100, fb[nm], same, plan["q_tile"]), flush=True)
         L._lib = libs["product"]
