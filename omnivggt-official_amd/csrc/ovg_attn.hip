@@ -308,7 +308,19 @@ Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
   if (v == 0) {
     const int64_t pad128 = (p.nq + 127) / 128 * 128, pad256 = (p.nq + 255) / 256 * 256;
     if (!bf16) v = p.nq >= 4096 ? 52 : 55;
-    else if (p.nq >= 4096) v = 2 * units512 >= 5 * (int64_t)cus ? 57 : 50;
+    else if (p.nq >= 4096) {
+      // Launches below 2.5 rounds of 512-row tiles: 256-row tiles (two workgroups per CU, 2 x CUs slots) or 128-row tiles (three per CU).
+      // r04 A/B, one process, 16 heads x S views (profiles/r04_attention_small_launches_ab.txt; 256-row / 128-row time in ms):
+      //   S = 3  0.101 / 0.090   4  0.133 / 0.121   5  0.179 / 0.210   6  0.309 / 0.283   7  0.380 / 0.364   8  0.414 / 0.456   10  0.660 / 0.670   12  0.994 / 1.008
+      // i.e. pure quantisation: 128-row tiles win when they need no more (ceil) rounds of their 3 x CUs slots than the 256-row tiles of their
+      // 2 x CUs slots AND either everything fits one round (more CUs busy) or their last round is at most ~65 % full (a fuller last round of
+      // three 4-wave workgroups per CU runs slower than the 256-row kernel's: S = 8, 1.79 rounds, -9 %).
+      const int64_t u256 = p.BH * ((p.nq + 255) / 256), u128 = p.BH * ((p.nq + 127) / 128);
+      const int64_t s256 = 2 * (int64_t)cus, s128 = 3 * (int64_t)cus;
+      const int64_t c256 = (u256 + s256 - 1) / s256, c128 = (u128 + s128 - 1) / s128;
+      const bool small128 = c128 <= c256 && (c128 == 1 || 100 * (c128 * s128 - u128) >= 35 * s128);
+      v = 2 * units512 >= 5 * (int64_t)cus ? 57 : (small128 ? 54 : 50);
+    }
     else v = (pad128 * 26 < pad256 * 25 && 2 * p.BH * (pad128 / 128) >= 15 * (int64_t)cus) ? 54 : 50;   // ... from 2.5 rounds of 3 x CUs slots on (8 views: 0.069 ms with 256-row, 0.072 with 128-row tiles)
   }
   pl.variant = v;

@@ -438,6 +438,9 @@ def test_attention_launch_plan_of_the_baseline_shapes():
     # single GPU, global attention (16 heads, nq = nk = S * 1374)
     p8 = plan(16, 8 * P, [8 * P], bf)
     assert (p8["q_tile"], p8["tail_q_tile"], p8["main_rows"]) == (256, 0, 8 * P)            # 1.34 rounds: the tail split loses there (-4 %)
+    # short global launches (r04 A/B): 128-row tiles where they quantise no worse than 256-row tiles and their last round is not too full
+    assert [plan(16, S * P, [S * P], bf)["q_tile"] for S in (3, 4, 5, 6, 7, 8, 12, 13)] == [128, 128, 256, 128, 128, 256, 256, 256]
+    assert plan(16, 4 * P, [4 * P], bf)["tail_q_tile"] == 0 and plan(16, 4 * P, [4 * P], bf)["splits"] == 1
     for S in (9, 10):
         p = plan(16, S * P, [S * P], bf)
         assert (p["q_tile"], p["tail_q_tile"], p["main_rows"]) == (256, 128, 8192), (S, p)     # one full round of 512 slots, then 128-row tiles
