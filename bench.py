@@ -21,7 +21,9 @@ At N=1 the same JSON line carries
   `secondary`    the 8-view configs[1] measurement (frames/s + roofline of the same kernel on that shape);
   `parity`       the timed 16-bit forward cross-checked against the parity-proven f32 mode of the SAME library on
                  the SAME inputs, per sampled layer, at 8 and at 64 views (max-rel and rms-rel) -- the headline
-                 number rests on verified outputs; the f32 mode's own throughput at 8 views rides along;
+                 number rests on verified outputs; the f32 mode's own throughput at 8 views rides along, and so does
+                 the split-f16 mode (`f32x_mode`: the <= 1e-4 mode with throughput -- its distance from the f32 mode per
+                 sampled layer and its frames/s at 8 and at 64 views);
   `cpu_baseline` the oracle (CPU restatement of the reference) timed on the host: one frame block + one global
                  block + one DINO block at the REAL 64-view shapes, extrapolated x24, plus a complete
                  2-view forward.
@@ -508,6 +510,18 @@ def parity_block(agg, dev, args, view_counts):
             f_total, _ = agg_flops(S)
             entry["f32_mode"] = {"frames_per_s": round(S / ms * 1e3, 3), "ms_per_step": round(ms, 3),
                                  "tflops": round(f_total / 1e12 / (ms * 1e-3), 1), "frac_of_f32_mfma_peak": round(f_total / 1e12 / (ms * 1e-3) / PEAK_TFLOPS["f32"], 4)}
+        # the <= 1e-4 mode WITH throughput (split-f16, lib.F32X) on the same inputs: its distance from the exact-f32 mode and its own rate
+        agg.set_compute_dtype(L.F32X)
+        xs = sample(run())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            run()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 2 * 1e3
+        entry["f32x_mode"] = {"max_rel_vs_f32_mode": [float("%.3e" % float((a - b).double().abs().max() / b.abs().max())) for a, b in zip(xs, ref)],
+                              "frames_per_s": round(S / ms * 1e3, 3), "ms_per_step": round(ms, 3),
+                              "what": "compute_dtype='f32x': (hi, lo) f16 planes, three f16 MFMAs per product; <= 1e-4 of the reference like the f32 mode (tests)"}
         out["S%d" % S] = entry
         del inp
         torch.cuda.empty_cache()
