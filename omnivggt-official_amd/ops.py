@@ -49,9 +49,6 @@ class HiLo:
         """f32 value of the pair (tests)."""
         return self.hi.float() + self.lo.float()
 
-    def rows(self, lo, hi):
-        return HiLo(self.planes[:, lo:hi])
-
 
 def empty_like_dtype(shape, dtype, device, zero=False):
     """Activation / weight storage for `dtype`: a plain tensor, or a HiLo pair of f16 planes in the split-f16 mode."""
