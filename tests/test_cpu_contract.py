@@ -118,6 +118,15 @@ def test_split_f16_mode_contract_on_cpu():
     assert bool((err[ok] <= bound[ok]).all()), float((err[ok] / bound[ok]).max())
     assert torch.isfinite(h.hi).all() and torch.isfinite(h.lo).all()                 # saturating, never inf
     assert abs(float(h.float()[-4]) - 70000.0) <= 32.0                                # hi = 65504, lo carries the rest
+    # the error model of a split contraction, emulated in torch: three products of f16 planes (exact in f32) accumulated in f32 against a
+    # float64 evaluation of the same f32 operands -- f32-roundoff class, three orders below a plain f16 GEMM
+    a32, b32 = torch.randn(256, 1024, generator=g), torch.randn(192, 1024, generator=g) * 0.03
+    ah, bh = ops.to_hilo(a32), ops.to_hilo(b32)
+    mm = lambda u, v: u.float() @ v.float().t()
+    got = mm(ah.lo, bh.hi) + mm(ah.hi, bh.lo) + mm(ah.hi, bh.hi)
+    ref = a32.double() @ b32.double().t()
+    rel = lambda t: float((t.double() - ref).abs().max() / ref.abs().max())
+    assert rel(got) <= 2e-6 and rel(mm(a32.half(), b32.half())) >= 1e-4, (rel(got), rel(mm(a32.half(), b32.half())))
     # argument validation (host side, before any launch)
     lib = L.load()
     fake = 0x10000
