@@ -152,7 +152,12 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[qb][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const u32x4 ones = OnesFrag<T>::get();
+  u32x4 ones = OnesFrag<T>::get();
+  // The all-ones A operand of the row-sum MFMAs must LIVE in registers: as a known constant hipcc may rematerialise it inside the loop
+  // (s_mov + v_mov_b64 directly in front of its use) -- harmless in front of a compiler-emitted MFMA, which gets its wait states, but in
+  // front of an `asm volatile` MFMA of the pinned body that is a VALU-write -> MFMA-read hazard nobody pads: the MFMA reads the stale
+  // register. (r04: exactly this broke the every-segment loop form -- 100 % verified-fallback re-runs.) Opaque to the optimiser from here on.
+  asm volatile("" : "+v"(ones));
 
   // ---- staging ------------------------------------------------------------------------------------------------------------
   // Register path (DMA = false): global loads of tile j + 1 are issued before the MFMAs of tile j and written to the other LDS
@@ -481,18 +486,17 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
     }
   };
   int j_all = 0;
-  // OVG_ATTN_PIPE_LOOP (A/B builds, tools/probes/build_alt.py): 1 (shipped) = the pinned body on the leading full tiles of a
-  // single-segment launch, 0 = compiler-scheduled body everywhere.
-  // Measured and NOT shipped (r04, profiles/r04_attn_ab_loop_forms.txt): the pinned loop for every full tile of every segment (pinned
-  // loop + one compiler-scheduled masked tile per segment inside an outer loop, for the multi-segment launches of the view-sharded run).
-  // Bit-wrong speculative pass: with that control flow hipcc (ROCm 7.2) stops coalescing the PB_PACK copies -- v_mov_b64 pairs appear
-  // directly in front of the consuming asm MFMA, inside the VALU-write -> MFMA-read hazard window the generator guarantees only for its
-  // own statements -- and a build with wait states owned by the packed fragment failed the same way, so there is at least one more
-  // ordering assumption that only holds for the straight-line form. EVERY workgroup failed its verification and re-ran (688 of 688
-  // fallback workgroups, 2.1x slower, results still exact) -- found by the fallback counter, invisible to every parity test.
+  // OVG_ATTN_PIPE_LOOP (A/B builds, tools/probes/build_alt.py): 2 (shipped) = the pinned body on every FULL tile of every segment,
+  // 1 = on the leading full tiles of single-segment launches only (the form of the first r04 passes), 0 = compiler-scheduled body everywhere.
+  // History of form 2 (profiles/r04_attn_ab_loop_forms.txt): its first build computed a WRONG speculative pass -- with the outer loop around
+  // the two bodies hipcc rematerialised the constant all-ones operand of the row-sum MFMAs inside the hot loop (s_mov + v_mov_b64 directly
+  // in front of the asm MFMA that reads it: a VALU-write -> MFMA-read hazard nobody pads for inline asm), every row sum was garbage, every
+  // workgroup failed its verification and re-ran (688 of 688, 2.1x slower, results exact, all parity tests green: found by the fallback
+  // counter). With `ones` made opaque to the optimiser (above) the form is bit-identical to form 1 and +5.0 % on the 8-segment per-rank
+  // launch of the view-sharded run (-0.3 ... -0.4 % on single-segment launches: noise level).
   // tests/test_attn_body_generator.py::test_pinned_hot_loops_hold_no_compiler_copies guards the shipped kernels against such copies.
 #ifndef OVG_ATTN_PIPE_LOOP
-#define OVG_ATTN_PIPE_LOOP 1
+#define OVG_ATTN_PIPE_LOOP 2
 #endif
 #if OVG_ATTN_PIPE_LOOP == 1
   if constexpr (PIPE) {
@@ -501,6 +505,18 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
     n_full = n_full < total_tiles ? n_full : total_tiles;
     for (; j_all < n_full; ++j_all) tile_iter(j_all, std::true_type{});
     asm volatile("s_nop 15\n\ts_nop 15");     // asm MFMA results -> VALU / builtin readers behind the loop (hipcc does not see the hazard)
+  }
+#elif OVG_ATTN_PIPE_LOOP == 2
+  if constexpr (PIPE) {
+    // Segment by segment (one segment on a single GPU; one per rank / source after a view-sharded exchange): the FULL tiles of the
+    // segment in a loop of the pinned body, then its masked last tile, if any, through the compiler-scheduled body (one call per segment)
+    while (j_all < total_tiles) {
+      int n_full = c_nk / BC - ctile;
+      n_full = n_full < total_tiles - j_all ? n_full : total_tiles - j_all;
+      for (int i = 0; i < n_full; ++i, ++j_all) tile_iter(j_all, std::true_type{});
+      asm volatile("s_nop 15\n\ts_nop 15");   // asm MFMA results -> VALU / builtin readers behind the loop
+      if (j_all < total_tiles && (ctile + 1) * BC > c_nk) { tile_iter(j_all, std::false_type{}); ++j_all; }
+    }
   }
 #endif
   for (; j_all < total_tiles; ++j_all) tile_iter(j_all, std::false_type{});
