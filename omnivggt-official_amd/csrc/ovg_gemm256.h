@@ -130,6 +130,7 @@ OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict_
     if (s < nk) stage(s);
   wait_tiles_in_flight(in_flight_after(0));
   __builtin_amdgcn_s_barrier();                      // P: tile 0 visible to every wave (NOT __syncthreads: its fence drains vmcnt to 0)
+  tl_mark(1);
 
   if (wm == 0) {
     for (int t = 0; t < nk; ++t) {

@@ -1006,7 +1006,7 @@ def main():
     print(L.load().ovg_build_info().decode(), torch.cuda.get_device_name(0), flush=True)
     tests = {"probe": test_probe, "layernorm": test_layernorm, "linear": lambda: test_linear(args.quick), "qkv": lambda: test_qkv(args.quick),
              "attn": lambda: test_attn(args.quick), "embed": test_embed, "block": lambda: test_block(args.quick),
-             "heads": lambda: test_heads(args.quick), "gemm256": lambda: test_gemm256(args.quick), "attn_big": lambda: test_attn_big(args.quick),
+             "heads": lambda: test_heads(args.quick), "gemm256": lambda: test_gemm256(args.quick), "gemm256p": lambda: test_gemm256(args.quick, tile=L.TILE_256P, auto_is=False), "attn_big": lambda: test_attn_big(args.quick),
              "lse_merge": test_attn_lse_merge, "camera": lambda: test_camera_head(timing=True), "f32x": lambda: test_f32x(args.quick), "fallback": test_attn_fallback_counter}
     for name, fn in tests.items():
         if args.only and name not in args.only.split(","):
