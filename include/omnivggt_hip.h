@@ -112,6 +112,9 @@ enum { OVG_TILE_AUTO = 0, OVG_TILE_128 = 1, OVG_TILE_256 = 2,
        /* persistent 256 x 256 (ABI 9): one workgroup per CU walks a balanced, row-granular share of the tiles, k-stage ring kept full across
         * tiles, chunked epilogues (ovg_gemm256p.h); plain 16-bit dtypes, N % 256 == 0, K % 128 == 0 (OVG_F16X2 runs OVG_TILE_256 instead) */
        OVG_TILE_256P = 4,
+       /* flag on OVG_TILE_256 / AUTO-resolved 256 x 256 launches: the k-stage DMA requests are issued between the MFMAs of the M sections
+        * instead of in the L sections (ovg_gemm256.h: DMA_M) */
+       OVG_TILE_DMA_M = 8, OVG_TILE_256M = 10,
        /* A/B flag, OR-ed onto any of the three: the same kernels with the r02 epilogue forms (erf_as GELU; per-lane 8- / 16-byte stores in
         * the accumulator layout instead of whole lines staged through the idle LDS -- ovg_gemm.hip) */
        OVG_TILE_R02_EPILOGUE = 16, OVG_TILE_128X = 17, OVG_TILE_256X = 18 };

@@ -53,7 +53,13 @@ OVG_DEV void wait_tiles_in_flight(int n) {     // leave at most n k-stages (4 DM
 // (the V^T tiles of the QKV projection: a lane then owns 4 CONSECUTIVE tokens of one feature = one 8-byte store)
 // X3 (OVG_F16X2): operands are (hi, lo) plane pairs and the ring streams 3 nk virtual k-stages -- x_lo * w_hi, x_hi * w_lo, x_hi * w_hi --
 // whose source planes are chosen per stage in stage(); everything else (ring, waits, ping-pong) is unchanged.
-template <typename T, bool SWAP = false, bool X3 = false>
+// DMA_M (round 5): the four LDS-DMA requests of a k-stage are issued INSIDE the M section, one behind every eighth MFMA, instead of in the
+// L section. Timeline + issue-cost arithmetic (profiles/r05_gemm_timeline.txt, MI355X_MICROARCH.md "LDS-DMA piece issue cost"): an L section is
+// 12 ds_read_b128 + 4 DMA requests at 100-185 cycles each = ~600 cycles, LONGER than the 544 cycles of the partner's 32 MFMAs, so the
+// barrier interval was paced by the loads; among MFMAs a request costs ~60 cycles of issue that the matrix pipe covers. The request for
+// k-stage t + 3 moves from L(t) to M(t) (later for both groups: the WAR argument above holds a fortiori); group 1's counted wait w(t + 1),
+// which sits in L(t) in front of M(t), now sees requests up to k-stage t + 2 only and leaves one stage in flight instead of two.
+template <typename T, bool SWAP = false, bool X3 = false, bool DMA_M = false>
 OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict__ W, int64_t ldw,
                       int M, int N, int K, int m0, int n0, unsigned char* lds, f32x4 (&acc)[4][8],
                       const T* __restrict__ Xlo = nullptr, const T* __restrict__ Wlo = nullptr) {
@@ -110,15 +116,37 @@ OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict_
 #pragma unroll
     for (int t = 0; t < 8; ++t) b[t] = *reinterpret_cast<const u32x4*>(base + x_off + t * 16 * ROWB);
   };
-  auto mfmas = [&]() {
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+  auto stage_piece = [&](int kt, int j) {          // DMA_M: request j = 0..3 of k-stage kt (W rows 0-15, X rows 0-15, W rows 16-31, X rows 16-31 of this wave's 32)
+    const uint32_t wb = lds_base + (kt & (SLOTS - 1)) * STAGE_B + wave * 32 * ROWB;
+    int64_t xo = (int64_t)kt * ROWB, wo = xo;
+    if constexpr (X3) {
+      const int pass = kt >= 2 * nk1 ? 2 : (kt >= nk1 ? 1 : 0);
+      const int64_t kb = (int64_t)(kt - pass * nk1) * ROWB;
+      xo = kb + (pass == 0 ? dxl : 0);
+      wo = kb + (pass == 1 ? dwl : 0);
+    }
+    const int i = j >> 1;
+    if (j & 1) lds_dma16(xg[i] + xo, wb + W_TILE + i * 16 * ROWB);
+    else lds_dma16(wg[i] + wo, wb + i * 16 * ROWB);
+  };
+  auto mfmas = [&](int kt_req = -1) {              // kt_req >= 0 (DMA_M): k-stage to request between the MFMAs
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
       for (int mt = 0; mt < 8; ++mt) {
         if constexpr (SWAP) TT<T>::mma(acc[nt][mt], b[mt], a[nt]);
         else TT<T>::mma(acc[nt][mt], a[nt], b[mt]);
+        if constexpr (DMA_M) {
+          if (mt == 3) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt_req >= 0) stage_piece(kt_req, nt);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       }
+    }
     __builtin_amdgcn_s_setprio(0);
   };
   auto in_flight_after = [&](int t) {   // k-stages issued beyond tile t when the wave has staged up to tile min(t + 2, nk - 1)
@@ -135,12 +163,12 @@ OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict_
   if (wm == 0) {
     for (int t = 0; t < nk; ++t) {
       read_frags(t);                                 // L(t)
-      if (t + 3 < nk) stage(t + 3);
+      if constexpr (!DMA_M) { if (t + 3 < nk) stage(t + 3); }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();                  // b(2t)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      mfmas();                                       // M(t)
+      if constexpr (DMA_M) mfmas(t + 3 < nk ? t + 3 : -1); else mfmas();   // M(t)
       __builtin_amdgcn_sched_barrier(0);
       if (t + 1 < nk) wait_tiles_in_flight(in_flight_after(t + 1));   // w(t+1): stages issued so far reach t+3
       __builtin_amdgcn_s_barrier();                  // b(2t+1)
@@ -150,13 +178,16 @@ OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict_
     __builtin_amdgcn_s_barrier();                    // b0: one barrier behind group 0
     for (int t = 0; t < nk; ++t) {
       read_frags(t);                                 // L(t)
-      if (t + 3 < nk) stage(t + 3);
+      if constexpr (!DMA_M) { if (t + 3 < nk) stage(t + 3); }
       __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < nk) wait_tiles_in_flight(in_flight_after(t + 1));   // w(t+1)
+      if (t + 1 < nk) {                              // w(t+1); DMA_M: requests so far reach k-stage t + 2 (M(t - 1))
+        if constexpr (DMA_M) wait_tiles_in_flight(((t + 2) < (nk - 1) ? (t + 2) : (nk - 1)) - (t + 1));
+        else wait_tiles_in_flight(in_flight_after(t + 1));
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                  // b(2t+1)
       __builtin_amdgcn_sched_barrier(0);
-      mfmas();                                       // M(t)
+      if constexpr (DMA_M) mfmas(t + 3 < nk ? t + 3 : -1); else mfmas();   // M(t)
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();                  // b(2t+2)
     }

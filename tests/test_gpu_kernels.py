@@ -79,13 +79,6 @@ def test_gemm256_r02_gelu_form_behind_the_knob():
     _assert_clean()
 
 
-def test_gemm256_persistent_kernels_every_epilogue_ragged_m():
-    """The persistent 256 x 256 GEMMs (ovg_gemm256p.h: balanced row-granular pieces, ring kept full across pieces, chunked epilogues):
-    every epilogue, ragged M, both 16-bit dtypes, the QKV projection in all three `part`s, forced with OVG_TILE_256P."""
-    st.test_gemm256(False, tile=L.TILE_256P, auto_is=False)
-    _assert_clean()
-
-
 def test_global_attention_at_bench_key_counts():
     """N = 10 992 / 21 984 in full, N = 87 936 on sampled rows: the launches the bench times."""
     st.test_attn_big(False)

@@ -76,6 +76,7 @@ for stage in "$@"; do
     sweep)      for v in 4 12 16 24 32 48; do
         timeout 600 python bench.py --views $v --steps 6 --warmup 2 --no-cpu-baseline --no-parity 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('views', d['config']['views'], 'frames/s', d['value'], 'ms', d['ms_per_step'], 'attention ms', d['roofline']['avg_launch_ms'], 'frac', d['roofline']['frac'], 'fallback', d['roofline']['fallback_workgroups'])"
       done 2>&1 | tee "$O/bench_view_sweep.txt" ;;
+    gemm_m)     (timeout 400 python tests/gpu_selftest.py --only gemm256m ${OVG_SELFTEST_ARGS:---quick} 2>&1 | grep -v amdgpu.ids | grep -E "FAIL|SELFTEST|Error|error|Traceback|raise|fault|core|gemm256m:" | head -60) | tee "$O/gemm256m_selftest.txt" ;;
     gemm_p)     (timeout 400 python tests/gpu_selftest.py --only gemm256p ${OVG_SELFTEST_ARGS:---quick} 2>&1 | grep -v amdgpu.ids | grep -E "FAIL|SELFTEST|Error|error|Traceback|raise|fault|core|gemm256p:" | head -60) | tee "$O/gemm256p_selftest.txt" ;;
     gemm_tl)    (timeout 900 python tools/probes/gemm_timeline.py ${OVG_TL_ARGS:-} 2>&1 | grep -v amdgpu.ids | tail -80) | tee "$O/gemm_timeline.txt" ;;
     gemm_ab)    (timeout 900 python tests/bench_kernels.py gemm ${OVG_GEMM_AB_ARGS:---views 8 16 64 --tiles 1 2 --rounds 3} 2>&1 | grep -v amdgpu.ids | tail -80) | tee "$O/gemm_ab.txt" ;;
