@@ -46,8 +46,11 @@ extern "C" {
  *    three f16 MFMAs hi*hi + hi*lo + lo*hi with f32 accumulation: ~2^-22 per product instead of 2^-8 (bf16) / 2^-11 (f16) at
  *    a third of the 16-bit MFMA rate; the `*_lo` pointers below, NULL / ignored for the other dtypes; single GPU and the K / V^T
  *    all-gather sharded form incl. ovg_attn_merge);
- *    ovg_attn_params.fallback_count / ovg_block_params.attn_fallback_count (telemetry of the speculative bf16 softmax) */
-#define OVG_ABI_VERSION 8
+ *    ovg_attn_params.fallback_count / ovg_block_params.attn_fallback_count (telemetry of the speculative bf16 softmax)
+ * 9: split-KV partials are f32 (ovg_attn_plan_out.part_bytes doubles) and a launch may split only the rows beyond its last full round
+ *    along the keys (key-split tail, reported through main_rows / tail_q_tile); OVG_TILE_256P / OVG_TILE_DMA_M name the round-5 lab GEMM
+ *    forms (OVG_E_UNSUPPORTED unless the library was built with -DOVG_LAB_GEMM) */
+#define OVG_ABI_VERSION 9
 
 enum { OVG_BF16 = 0, OVG_F16 = 1, OVG_F32 = 2,
        /* split-f16 ("f32x", the <= 1e-4 mode with throughput): a value x is stored as hi = f16(x) (saturated at +-65504) in the tensor the
@@ -205,7 +208,11 @@ typedef struct {
    * a second (tiny) launch combines them exactly. kv_splits: 0 = the library decides (ovg_attn_plan; never splits
    * when ws_part / ws_lse are NULL), 1 = never, 2..8 = force. ws_part: `part_bytes`, ws_lse: `lse_bytes` of ovg_attn_plan.
    * Units of one (batch entry, split) run next to each other, so the K / V^T range an XCD streams shrinks by kv_splits.
-   * ws_part_bytes / ws_lse_bytes: sizes of the two buffers; a call whose plan needs more than it was given is OVG_E_ARG. */
+   * ws_part_bytes / ws_lse_bytes: sizes of the two buffers; a call whose plan needs more than it was given is OVG_E_ARG.
+   * ABI 9: the partials are f32 (normalised O per key range + its log-sum-exp: a split launch now agrees with the unsplit one to ~1e-6
+   * before the final rounding; the 16-bit partials of ABI <= 8 were 6.9e-3 apart), so part_bytes doubled; and with kv_splits == 0 a launch
+   * with a fractional last round may run its full rounds unsplit and only the remaining rows cut along the keys ("key-split tail":
+   * ovg_attn_plan_out.main_rows < nq with tail_q_tile == q_tile), whose workspace covers those rows only. */
   int kv_splits; void* ws_part; float* ws_lse; int64_t ws_part_bytes; int64_t ws_lse_bytes;
   /* OVG_F16X2: lo planes of q and out (same shapes / strides). That mode runs one launch of 256-row tiles: no split-KV, no kv_heads /
    * head-major output (OVG_E_UNSUPPORTED), lse is available. */

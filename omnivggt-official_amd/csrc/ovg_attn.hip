@@ -277,7 +277,8 @@ int launch_attn(const ovg_attn_params& p, hipStream_t st) {
 // 64 views +3 %, 8 views -17 % -- profiles/r02_attention_dma_ab.txt), with the rows beyond the last full round in a second
 // launch of 128-row tiles (dispatch16).
 struct Plan16 { int variant; int bq; int splits; int per_split; int total_tiles;
-                int64_t main_rows; int tail_bq; };   // tail split: rows [0, main_rows) of every entry in the first launch (bq-row tiles), the rest in a second one of tail_bq-row tiles (0 = none)
+                int64_t main_rows; int tail_bq;      // tail split: rows [0, main_rows) of every entry in the first launch (bq-row tiles), the rest in a second one of tail_bq-row tiles (0 = none)
+                int tail_splits; };                  // key-split tail (round 5): the rest as bq-row tiles cut into tail_splits key ranges + merge (0 = none; excludes tail_bq)
 
 int cu_count_attn() {
   static const int n = [] {
@@ -297,8 +298,11 @@ int total_key_tiles(const ovg_attn_params& p) {
 Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
   Plan16 pl{};
   int v = p.variant;
+  int kvs = p.kv_splits, forced_tail = 0;      // A/B tool: variant 73 + kv_splits s = the key-split tail with exactly s key ranges
+  if (v == 73 && kvs > 1) { forced_tail = kvs; kvs = 0; }
   if (v == 71) v = 57;            // A/B tool: the 512-row kernel with its tail split (dispatch16)
   if (v == 72) v = 50;            // A/B tool: the 256-row kernel with a tail split (dispatch16)
+  if (v == 73) v = 50;            // A/B tool: the 256-row kernel with a key-split tail (dispatch16)
   const int cus = cu_count_attn();
   const int64_t units512 = p.BH * ((p.nq + 511) / 512);
   // 512-row tiles (8 waves, one workgroup per CU, barrier every 2 tiles) from ~2.5 rounds of them on: 16 views +5.9 %, 64 views +3 %
@@ -329,8 +333,8 @@ Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
   const int slots = (v == 33 || v == 51 || v == 57 || v == 58 || v == 59) ? cus : 2 * cus;
   const int64_t units = p.BH * ((p.nq + pl.bq - 1) / pl.bq);
   int splits = 1;
-  if (p.kv_splits > 1) splits = p.kv_splits;
-  else if (p.kv_splits == 0 && have_ws && (v == 21 || v == 6 || v == 50 || v == 52 || v == 54 || v == 55)) {   // two-workgroups-per-CU kernels (the 512-row ones have the tail split)
+  if (kvs > 1) splits = kvs;
+  else if (kvs == 0 && have_ws && (v == 21 || v == 6 || v == 50 || v == 52 || v == 54 || v == 55)) {   // two-workgroups-per-CU kernels (the 512-row ones have the tail split)
     // Measured model (LDS-DMA kernels, profiles/r02_attention_splitkv_ab.txt second block): a launch of R = units / slots rounds runs at
     // eff(R) = 1 - 0.2035 / R^0.72 of the many-round rate of 1.33 PFLOP/s (0.835 at R = 1.34, 0.88-0.90 at 2.7, 0.94-0.95 at 5.4, 0.963 at
     // 10.75: measured at 8 / 16 / 32 / 64 views and on the per-rank launch of the 8-GPU run); a split costs ~1.5 key tiles per unit plus the
@@ -377,7 +381,35 @@ Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
                               : (p.variant == 72 ? (full >= 1 && frac > 0.05) : (full == 1 && frac > 0.5));
     if (want && frac < 0.85 && rows_a > 0 && rows_a < p.nq) { pl.main_rows = rows_a; pl.tail_bq = 128; }
   }
+  // ---- key-split tail (round 5; unsplit launches of the two-workgroups-per-CU 256-row kernels, workspace given) ----
+  // A launch of R = units / slots rounds with a small fractional last round leaves most CUs idle for that round's whole length (13 views: 1120
+  // units on 512 slots, 2.19 rounds). The full rounds run unsplit; the rows beyond them run as the same 256-row tiles cut into s key ranges
+  // (the tail launch is then at most one round of short units) + the exact log-sum-exp merge on those rows only. Unlike a whole-launch
+  // split the partials cover the tail rows only (13 views: 96 of 1120 units).
+  pl.tail_splits = 0;
+  if (pl.splits == 1 && pl.tail_bq == 0 && have_ws && kvs == 0 && (v == 50 || v == 52) && (p.variant == 0 || p.variant == 73) && p.nq >= 4096) {
+    const int tslots = 2 * cus;
+    const int64_t full = units / tslots, rest = units - full * tslots;     // units of the fractional last round
+    const double frac = (double)rest / tslots;
+    const int64_t rows_a = full * tslots / p.BH * pl.bq;
+    // s key ranges per tail unit so that the tail launch stays within ONE round of slots (8 views: 176 units -> 2 ranges = 352 pieces; 3 ranges =
+    // 528 pieces on 512 slots measured 5 % SLOWER than the unsplit launch, profiles/r05_attention_keytail_ab.txt)
+    int s = forced_tail ? forced_tail : (rest > 0 ? (int)(tslots / rest) : 1);
+    s = s > OVG_MAX_SEG ? OVG_MAX_SEG : s;
+    while (s > 2 && (pl.total_tiles + s - 1) / s < 16) --s;
+    // measured (profiles/r05_attention_keytail_ab.txt, r05_attention_keytail_factors_ab.txt; unsplit -> key-split tail, ms): 13 views (2.19 rounds)
+    // 1.168 -> 1.089 (+7 %), 14 views (2.38) 1.274 -> 1.264 at best, 8 views (1.34) 0.443 -> 0.440 at best and 0.457 with the one-round factor:
+    // a last round that is a third full or more already runs fast on its lone workgroups. So: a tail of at most a quarter of a round.
+    const bool want = p.variant == 73 ? (full >= 1 && rest > 0) : (full >= 1 && full <= 3 && frac >= 0.05 && frac <= 0.25);
+    if (want && s >= 2 && rows_a > 0 && rows_a < p.nq && (pl.total_tiles + s - 1) / s >= 16) { pl.main_rows = rows_a; pl.tail_splits = s; }
+  }
   return pl;
+}
+
+// rows per entry of the split workspace for a split launch over q rows [row0, row1): the whole (padded) sequence when the launch starts at
+// row 0 -- the layout callers of rounds 2-4 sized their buffers for -- else the launch's own rows padded to its q tile
+int64_t split_part_rows(const ovg_attn_params& p, int bq, int64_t row0, int64_t row1) {
+  return row0 == 0 ? p.nq_pad : (row1 - row0 + bq - 1) / bq * bq;
 }
 
 template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false, int DMA = 0, bool X3 = false>
@@ -385,13 +417,13 @@ int launch_attn16(const ovg_attn_params& p, const Plan16& pl, hipStream_t st, in
   constexpr int BQ = 16 * QB * WAVES;
   if (row1 < 0) row1 = p.nq;
   const int nqt = (int)((row1 - row0 + BQ - 1) / BQ);
+  const int part_rows = (int)split_part_rows(p, BQ, row0, row1);
   const dim3 grid((unsigned)(p.BH * nqt * pl.splits)), block(64 * WAVES);
-  OVG_LAUNCH((attn16_kernel<T, QB, WAVES, MODE, OCC, VSUM, DMA, X3>), grid, block, 0, st, p, nqt, pl.total_tiles, pl.splits, pl.per_split, (int)row0);
+  OVG_LAUNCH((attn16_kernel<T, QB, WAVES, MODE, OCC, VSUM, DMA, X3>), grid, block, 0, st, p, nqt, pl.total_tiles, pl.splits, pl.per_split, (int)row0, part_rows);
   OVG_CHECK_LAUNCH();
   if (pl.splits > 1) {
-    const int64_t total = p.BH * p.nq * 8;
-    const int64_t blocks = (total + 255) / 256;
-    OVG_LAUNCH((attn_split_merge_kernel<T>), dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, p, pl.splits, total);
+    const int64_t blocks = (p.BH * (row1 - row0) * 8 + 255) / 256;
+    OVG_LAUNCH((attn_split_merge_kernel<T>), dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, p, pl.splits, (int)row0, (int)(row1 - row0), part_rows);
     OVG_CHECK_LAUNCH();
   }
   return OVG_OK;
@@ -416,10 +448,20 @@ template <typename T>
 int dispatch16(const ovg_attn_params& p, hipStream_t st) {
   constexpr bool kBf16 = std::is_same<T, bf16_t>::value;
   const Plan16 pl = plan16(p, kBf16, p.ws_part != nullptr && p.ws_lse != nullptr);
-  if (pl.splits > 1) {   // the partials go to caller memory: refuse a missing or undersized workspace instead of writing past it
+  if (pl.splits > 1 || pl.tail_splits > 1) {   // the partials go to caller memory: refuse a missing or undersized workspace instead of writing past it
     if (p.ws_part == nullptr || p.ws_lse == nullptr) return OVG_E_ARG;
-    const int64_t rows = (int64_t)pl.splits * p.BH * p.nq_pad;
-    if (p.ws_part_bytes < rows * OVG_D * 2 || p.ws_lse_bytes < rows * 4) return OVG_E_ARG;
+    const int64_t rows = pl.splits > 1 ? (int64_t)pl.splits * p.BH * p.nq_pad
+                                       : (int64_t)pl.tail_splits * p.BH * split_part_rows(p, pl.bq, pl.main_rows, p.nq);
+    if (p.ws_part_bytes < rows * OVG_D * 4 || p.ws_lse_bytes < rows * 4) return OVG_E_ARG;
+  }
+  if (pl.tail_splits > 1) {                         // key-split tail (plan16): full rounds unsplit, then the remaining rows cut along the keys + merge
+    const bool lazy = pl.variant == 52;             // f16 default: lazy-rescale body
+    int rc = lazy ? launch_attn16<T, 4, 4, 1, 2, false, 3>(p, pl, st, 0, pl.main_rows) : launch_attn16<T, 4, 4, 0, 2, false, 3>(p, pl, st, 0, pl.main_rows);
+    if (rc != OVG_OK) return rc;
+    Plan16 tp = pl;
+    tp.per_split = (pl.total_tiles + pl.tail_splits - 1) / pl.tail_splits;
+    tp.splits = (pl.total_tiles + tp.per_split - 1) / tp.per_split;
+    return lazy ? launch_attn16<T, 4, 4, 1, 2, false, 3>(p, tp, st, pl.main_rows, p.nq) : launch_attn16<T, 4, 4, 0, 2, false, 3>(p, tp, st, pl.main_rows, p.nq);
   }
   if (pl.tail_bq) {                                 // tail split (plan16): full rounds of big tiles, then the remaining rows as 128-row tiles
     const int rc = pl.variant == 57 ? launch_attn16<T, 4, 8, 0, 2, false, 5>(p, pl, st, 0, pl.main_rows)
@@ -457,7 +499,7 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
 int dispatch_x3(const ovg_attn_params& p, hipStream_t st) {
   Plan16 pl{};
   pl.variant = 90; pl.bq = 256; pl.splits = 1; pl.total_tiles = total_key_tiles(p); pl.per_split = pl.total_tiles;
-  pl.main_rows = p.nq; pl.tail_bq = 0;
+  pl.main_rows = p.nq; pl.tail_bq = 0; pl.tail_splits = 0;
   return launch_attn16<f16_t, 2, 8, 1, 2, true, 3, true>(p, pl, st);
 }
 
@@ -507,8 +549,15 @@ extern "C" int ovg_attn_plan(const ovg_attn_params* p, ovg_attn_plan_out* out) {
   const int64_t nq_pad = p->nq_pad >= p->nq ? p->nq_pad : ((p->nq + BC - 1) / BC) * BC;
   out->splits = pl.splits; out->q_tile = pl.bq; out->main_rows = pl.main_rows; out->tail_q_tile = pl.tail_bq;
   if (pl.splits > 1) {
-    out->part_bytes = (int64_t)pl.splits * p->BH * nq_pad * OVG_D * 2;
+    out->part_bytes = (int64_t)pl.splits * p->BH * nq_pad * OVG_D * 4;      // f32 partials (ABI 9; bf16 / f16 before)
     out->lse_bytes = (int64_t)pl.splits * p->BH * nq_pad * 4;
+  } else if (pl.tail_splits > 1) {                  // key-split tail: `splits` key ranges for the rows [main_rows, nq) only, tail_q_tile == q_tile
+    ovg_attn_params q = *p;
+    q.nq_pad = nq_pad;
+    const int64_t rows = split_part_rows(q, pl.bq, pl.main_rows, p->nq);
+    out->splits = pl.tail_splits; out->tail_q_tile = pl.bq;
+    out->part_bytes = (int64_t)pl.tail_splits * p->BH * rows * OVG_D * 4;
+    out->lse_bytes = (int64_t)pl.tail_splits * p->BH * rows * 4;
   }
   return OVG_OK;
 }

@@ -531,10 +531,12 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
 }
 
 // Normalise and store a wave's QB x 16 rows: the caller's final layout (token-major or head-major, + optional log-sum-exp)
-// or, in a split-KV pass, the head-major partial [split][entry][nq_pad][64] with its log-sum-exp.
+// or, in a split-KV pass, the head-major partial [split][entry][part_rows][64] (f32 since round 5: the bf16 partials of rounds 2-4 were an
+// extra rounding point, 6.9e-3 between a split and an unsplit launch of the same call; now ~1e-6 before the final rounding) with its
+// log-sum-exp. Partial rows are relative to q_row0, the first row of the launch (the key-split tail launch covers rows [q_row0, nq) only).
 template <typename T, int QB, bool X3 = false>
 OVG_DEV void write_out(const ovg_attn_params& p, const f32x4 (&o)[QB][4], const f32x4 (&lacc)[QB], const f32x4 (&negm)[QB],
-                       const int bh, const int q0, const int sp, const int splits) {
+                       const int bh, const int q0, const int sp, const int splits, const int q_row0 = 0, const int part_rows = 0) {
   const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
   const int nq = (int)p.nq;
   const int bq = bh / OVG_H, hh = bh % OVG_H;
@@ -543,12 +545,11 @@ OVG_DEV void write_out(const ovg_attn_params& p, const f32x4 (&o)[QB][4], const 
     const float inv = 1.0f / lacc[qb][0];        // every row of the ones-MFMA holds the full row sum
     const int q = q0 + qb * 16 + lr;
     if (q < nq) {
-      if (splits > 1) {                           // partial pass: head-major [split][entry][nq_pad][64] + its log-sum-exp
-        const int64_t row = ((int64_t)sp * p.BH + bh) * p.nq_pad + q;
-        T* dst = static_cast<T*>(p.ws_part) + row * OVG_D + 4 * g;
+      if (splits > 1) {                           // partial pass: head-major f32 [split][entry][part_rows][64] + its log-sum-exp
+        const int64_t row = ((int64_t)sp * p.BH + bh) * part_rows + (q - q_row0);
+        float* dst = static_cast<float*>(p.ws_part) + row * OVG_D + 4 * g;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-          store4<T>(dst + 16 * dt, o[qb][dt][0] * inv, o[qb][dt][1] * inv, o[qb][dt][2] * inv, o[qb][dt][3] * inv);
+        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(dst + 16 * dt) = o[qb][dt] * inv;
         if (g == 0) p.ws_lse[row] = __builtin_amdgcn_logf(lacc[qb][0]) - negm[qb][0];
         continue;
       }
@@ -569,7 +570,7 @@ OVG_DEV void write_out(const ovg_attn_params& p, const f32x4 (&o)[QB][4], const 
 
 // MODE: 0 = speculative anchored softmax + verified fallback, 1 = lazy-rescale only, 2 = forced fallback (tests)
 template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false, int DMA = 0, bool X3 = false>   // OCC: minimum waves per SIMD the register allocation must allow; X3: split-f16 planes (run_tiles)
-__global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params p, int nqt, int total_tiles, int splits, int per_split, int q_row0) {   // q tiles [0, nqt) of the rows starting at q_row0
+__global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params p, int nqt, int total_tiles, int splits, int per_split, int q_row0, int part_rows) {   // q tiles [0, nqt) of the rows starting at q_row0; part_rows: rows per entry of the split workspace
   static_assert(sizeof(T) == 2, "16-bit types only");
   constexpr int RB = 128, KT_B = BC * RB, VT_B = OVG_D * RB, BQ = 16 * QB * WAVES;
   __shared__ __attribute__((aligned(16))) unsigned char lds[(DMA ? DMA : 2) * (X3 ? 2 : 1) * (KT_B + VT_B)];
@@ -606,41 +607,42 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params
     }
   }
 
-  attn16::write_out<T, QB, X3>(p, o, lacc, negm, bh, q0, sp, splits);
+  attn16::write_out<T, QB, X3>(p, o, lacc, negm, bh, q0, sp, splits, q_row0, part_rows);
 }
 
 // Second launch of a split-KV call: out[entry, q, :] = sum_s w_s part[s][entry, q, :] / sum_s w_s, w_s = 2^(lse_s - max lse)
-// (exact: softmax over disjoint key sets combines through the log-sum-exps). One thread = 8 features (16 bytes) of one
-// (entry, query); writes the caller's final layout (token-major or head-major) and, if asked, the total log-sum-exp.
+// (exact: softmax over disjoint key sets combines through the log-sum-exps) for the rows [row0, row0 + nrows) of every entry -- all of
+// them after a whole-launch split, the tail rows after a key-split tail launch. One thread = 8 features (two f32x4) of one (entry, query);
+// writes the caller's final layout (token-major or head-major) and, if asked, the total log-sum-exp.
 template <typename T>
-__global__ __launch_bounds__(256) void attn_split_merge_kernel(ovg_attn_params p, int splits, int64_t total) {
+__global__ __launch_bounds__(256) void attn_split_merge_kernel(ovg_attn_params p, int splits, int row0, int nrows, int part_rows) {
+  const int64_t total = (int64_t)p.BH * nrows * 8;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     const int c = (int)(idx & 7);
-    const int64_t rq = idx >> 3;                       // entry * nq + q
-    const int bh = (int)(rq / p.nq), q = (int)(rq - (int64_t)bh * p.nq);
-    const int64_t row = (int64_t)bh * p.nq_pad + q, stride = p.BH * p.nq_pad;
+    const int64_t rq = idx >> 3;                       // entry * nrows + local row
+    const int bh = (int)(rq / nrows), ql = (int)(rq - (int64_t)bh * nrows), q = row0 + ql;
+    const int64_t row = (int64_t)bh * part_rows + ql, stride = p.BH * (int64_t)part_rows;
     float l[OVG_MAX_SEG], m = -INFINITY;
 #pragma unroll
     for (int s = 0; s < OVG_MAX_SEG; ++s)
       if (s < splits) { l[s] = p.ws_lse[s * stride + row]; m = fmaxf(m, l[s]); }
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, wsum = 0.f;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float wsum = 0.f;
 #pragma unroll
     for (int s = 0; s < OVG_MAX_SEG; ++s)
       if (s < splits) {
         const float w = __builtin_amdgcn_exp2f(l[s] - m);
         wsum += w;
-        const u32x4 raw = *reinterpret_cast<const u32x4*>(static_cast<const T*>(p.ws_part) + (s * stride + row) * OVG_D + c * 8);
-        T v[8];
-        __builtin_memcpy(v, &raw, 16);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] += w * TT<T>::to_f32(v[i]);
+        const float* src = static_cast<const float*>(p.ws_part) + (s * stride + row) * OVG_D + c * 8;
+        acc0 += w * *reinterpret_cast<const f32x4*>(src);
+        acc1 += w * *reinterpret_cast<const f32x4*>(src + 4);
       }
     const float inv = 1.0f / wsum;
     const int bq = bh / OVG_H, hh = bh % OVG_H;
     T* dst = p.out_bh_stride > 0 ? static_cast<T*>(p.out) + (int64_t)bh * p.out_bh_stride + (int64_t)q * p.ldo + c * 8
                                  : static_cast<T*>(p.out) + ((int64_t)bq * p.nq + q) * p.ldo + hh * OVG_D + c * 8;
-    store4<T>(dst, acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
-    store4<T>(dst + 4, acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv);
-    if (p.lse != nullptr && c == 0) p.lse[row] = m + __builtin_amdgcn_logf(wsum);
+    store4<T>(dst, acc0[0] * inv, acc0[1] * inv, acc0[2] * inv, acc0[3] * inv);
+    store4<T>(dst + 4, acc1[0] * inv, acc1[1] * inv, acc1[2] * inv, acc1[3] * inv);
+    if (p.lse != nullptr && c == 0) p.lse[(int64_t)bh * p.nq_pad + q] = m + __builtin_amdgcn_logf(wsum);
   }
 }

@@ -842,6 +842,41 @@ def test_attn_lse_merge():
     h0 = ops.flash_attn(qd, [(kd, vtd, n)], n, torch.bfloat16, variant=0, head_major=True)
     report("attn_tailsplit_bf16_S16_headmajor", h0[:, :n].permute(1, 0, 2).reshape(n, 1024), o1, TOL["bf16"])
     del qd, kd, vtd, o0, o1, h0
+    # key-split tail of the automatic plan (13 views = 2.19 rounds of 256-row tiles -> 16384 rows unsplit + 1478 rows cut into 5 key ranges + merge;
+    # 8 views = 1.34 rounds: not taken automatically, forced here through the A/B variant 73): outputs and log-sum-exps against the baseline kernel and against the SAME kernel unsplit
+    # (f32 partials: the split rows must agree with the unsplit launch to 1e-3, round-4 review item 4), token-major and head-major, bf16 and f16
+    for name, dt, S, kt_variant, kt_splits in (("bf16", torch.bfloat16, 13, 0, 0), ("f16", torch.float16, 13, 0, 0), ("bf16", torch.bfloat16, 8, 73, 2)):   # last: forced (A/B knob)
+        BH, n = 16, S * 1374
+        qd, kd, vtd = ops.alloc_qkv(BH, n, n, dt, DEV)
+        qd[:, :n] = (rnd(BH, n, 64, g=g2) * 1.3).to(dt).to(DEV)
+        kd[:, :n] = rnd(BH, n, 64, g=g2).to(dt).to(DEV)
+        ops.set_vt(vtd, rnd(BH, 64, n, g=g2).to(dt))
+        plan = ops.attn_plan(BH, n, [n], dt, kt_variant, kt_splits, nq_pad=qd.shape[1])
+        ok_plan = plan["splits"] > 1 and plan["main_rows"] < n and plan["tail_q_tile"] == plan["q_tile"] == 256
+        results.append({"name": "attn_keytail_%s_S%d_plan" % (name, S), "ok": bool(ok_plan), "rel": 0.0})
+        print("[%s] attn_keytail_%s_S%d plan %s" % ("PASS" if ok_plan else "FAIL", name, S, plan), flush=True)
+        ws = ops.alloc_split_ws(plan, DEV)
+        l1 = torch.full((BH, qd.shape[1]), float("nan"), device=DEV)
+        l0 = torch.full((BH, qd.shape[1]), float("nan"), device=DEV)
+        o1 = ops.flash_attn(qd, [(kd, vtd, n)], n, dt, variant=1, lse=l1)
+        o0 = ops.flash_attn(qd, [(kd, vtd, n)], n, dt, variant=kt_variant, kv_splits=kt_splits, lse=l0, split_ws=ws)
+        ou = ops.flash_attn(qd, [(kd, vtd, n)], n, dt, variant=0, kv_splits=1)
+        report("attn_keytail_%s_S%d_out" % (name, S), o0, o1, TOL[name])
+        report("attn_keytail_%s_S%d_lse" % (name, S), l0[:, :n], l1[:, :n], 2e-3)
+        # split rows vs the unsplit launch: f32 partials + exact merge; what remains is the 16-bit rounding of P against a different softmax
+        # anchor per key range and the final rounding: at most one ulp of the output -- 2^-8 (bf16) / 2^-11 (f16) of the value (bf16 partials: 6.9e-3)
+        report("attn_keytail_%s_S%d_vs_unsplit" % (name, S), o0, ou.float(), 4e-3 if name == "bf16" else 1e-3)
+        frac_diff = float((o0 != ou).float().mean())
+        print("       attn_keytail_%s_S%d: %.2f %% of the outputs differ from the unsplit launch (speculative-softmax anchors differ per key range: P rounds differently)" % (name, S, 100 * frac_diff), flush=True)
+        h0 = ops.flash_attn(qd, [(kd, vtd, n)], n, dt, variant=kt_variant, kv_splits=kt_splits, head_major=True, split_ws=ws)
+        report("attn_keytail_%s_S%d_headmajor" % (name, S), h0[:, :n].permute(1, 0, 2).reshape(n, 1024), o1, TOL[name])
+        try:                                                   # the tail workspace is checked like the whole-launch one
+            ops.flash_attn(qd, [(kd, vtd, n)], n, dt, variant=kt_variant, kv_splits=kt_splits, split_ws=(ws[0][: ws[0].numel() // 2], ws[1]))
+            results.append({"name": "attn_keytail_%s_S%d_small_ws_refused" % (name, S), "ok": False, "rel": float("nan")})
+            print("[FAIL] undersized key-split tail workspace accepted")
+        except L.OvgError:
+            results.append({"name": "attn_keytail_%s_S%d_small_ws_refused" % (name, S), "ok": True, "rel": 0.0})
+        del qd, kd, vtd, o0, o1, ou, h0, ws
     # split-KV: forced 2..8 key splits (+ the library's own plan) == the single-pass result, token-major and head-major,
     # ragged multi-segment key lists, with the total log-sum-exp output
     for name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):

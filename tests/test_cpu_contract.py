@@ -450,6 +450,12 @@ def test_attention_launch_plan_of_the_baseline_shapes():
     # short global launches (r04 A/B): 128-row tiles where they quantise no worse than 256-row tiles and their last round is not too full
     assert [plan(16, S * P, [S * P], bf)["q_tile"] for S in (3, 4, 5, 6, 7, 8, 12, 13)] == [128, 128, 256, 128, 128, 256, 256, 256]
     assert plan(16, 4 * P, [4 * P], bf)["tail_q_tile"] == 0 and plan(16, 4 * P, [4 * P], bf)["splits"] == 1
+    # key-split tail (round 5): a last round that is at most a quarter full -- 13 views, 2.19 rounds of 256-row tiles: 2 rounds (16384 rows) unsplit,
+    # the remaining 1478 rows (96 units) as 5 key ranges each + merge, f32 partials sized for the tail rows only; not at 8 (1.34) / 14 (2.38) views
+    p13 = plan(16, 13 * P, [13 * P], bf)
+    assert (p13["q_tile"], p13["tail_q_tile"], p13["main_rows"], p13["splits"]) == (256, 256, 16384, 5), p13
+    assert p13["part_bytes"] == 5 * 16 * 1536 * 64 * 4 and p13["lse_bytes"] == 5 * 16 * 1536 * 4
+    assert plan(16, 13 * P, [13 * P], bf, kv_splits=1)["splits"] == 1 and plan(16, 14 * P, [14 * P], bf)["splits"] == 1
     for S in (9, 10):
         p = plan(16, S * P, [S * P], bf)
         assert (p["q_tile"], p["tail_q_tile"], p["main_rows"]) == (256, 128, 8192), (S, p)     # one full round of 512 slots, then 128-row tiles
@@ -462,6 +468,6 @@ def test_attention_launch_plan_of_the_baseline_shapes():
     assert plan(64 * 16, P, [P], bf)["q_tile"] == 128 and plan(8 * 16, P, [P], bf)["q_tile"] == 256
     # per-rank launches of the 8-GPU run, head-parallel form: 16 (source rank, head) entries x 8 views of queries x 8 segments of keys
     pr = plan(16, 8 * P, [8 * P] * 8, bf)
-    assert (pr["splits"], pr["q_tile"], pr["tail_q_tile"]) == (4, 256, 0) and pr["part_bytes"] == 4 * 16 * ops.pad_to(8 * P, 64) * 64 * 2
+    assert (pr["splits"], pr["q_tile"], pr["tail_q_tile"]) == (4, 256, 0) and pr["part_bytes"] == 4 * 16 * ops.pad_to(8 * P, 64) * 64 * 4
     # a forced factor is honoured and sized; the baseline kernel (variant 1) never splits
     assert plan(16, 8 * P, [8 * P], bf, kv_splits=3)["splits"] == 3 and plan(16, 8 * P, [8 * P], bf, variant=1)["splits"] == 1

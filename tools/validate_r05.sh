@@ -76,6 +76,8 @@ for stage in "$@"; do
     sweep)      for v in 4 12 16 24 32 48; do
         timeout 600 python bench.py --views $v --steps 6 --warmup 2 --no-cpu-baseline --no-parity 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('views', d['config']['views'], 'frames/s', d['value'], 'ms', d['ms_per_step'], 'attention ms', d['roofline']['avg_launch_ms'], 'frac', d['roofline']['frac'], 'fallback', d['roofline']['fallback_workgroups'])"
       done 2>&1 | tee "$O/bench_view_sweep.txt" ;;
+    attn_st)    (timeout 900 python tests/gpu_selftest.py --only attn,attn_big,lse_merge,fallback 2>&1 | grep -v amdgpu.ids | grep -E "FAIL|SELFTEST|Error|error|Traceback|raise|fault|core|keytail|\(attn" | head -80) | tee "$O/attn_selftest.txt" ;;
+    attn_ab8)   (timeout 900 python tests/bench_kernels.py attn --modes global --views ${OVG_AB_VIEWS:-8 9 10 12 13} --variants ${OVG_AB_VARIANTS:-0 50} --kv-splits ${OVG_AB_SPLITS:-0 1} --rounds 4 --target-ms 30 2>&1 | grep -v amdgpu.ids | tail -40) | tee "$O/attn_keytail_ab.txt" ;;
     gemm_m)     (timeout 400 python tests/gpu_selftest.py --only gemm256m ${OVG_SELFTEST_ARGS:---quick} 2>&1 | grep -v amdgpu.ids | grep -E "FAIL|SELFTEST|Error|error|Traceback|raise|fault|core|gemm256m:" | head -60) | tee "$O/gemm256m_selftest.txt" ;;
     gemm_p)     (timeout 400 python tests/gpu_selftest.py --only gemm256p ${OVG_SELFTEST_ARGS:---quick} 2>&1 | grep -v amdgpu.ids | grep -E "FAIL|SELFTEST|Error|error|Traceback|raise|fault|core|gemm256p:" | head -60) | tee "$O/gemm256p_selftest.txt" ;;
     gemm_tl)    (timeout 900 python tools/probes/gemm_timeline.py ${OVG_TL_ARGS:-} 2>&1 | grep -v amdgpu.ids | tail -80) | tee "$O/gemm_timeline.txt" ;;
