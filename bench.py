@@ -57,8 +57,8 @@ P_TOK, C = 1374, 1024
 # MI355X_MICROARCH.md, dense MFMA. f32x (split-f16, three f16 MFMAs per product): a third of the f16 peak per ALGORITHMIC flop
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f32x": 2500.0 / 3.0}
 DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f32x": L.F32X}
-KERNEL_NAME = {"bf16": "attn16_kernel<bf16,QB=4,WAVES=%d,MODE=0> (speculative anchored softmax + verified fallback; K/V^T tiles by LDS-DMA; %d-row q tiles)",
-               "f16": "attn16_kernel<f16,QB=4,WAVES=%d,MODE=1> (lazy-rescale online softmax; K/V^T tiles by LDS-DMA; %d-row q tiles)",
+KERNEL_NAME = {"bf16": "attn16_kernel<bf16,QB=%d,WAVES=%d,MODE=0> (speculative anchored softmax + verified fallback; K/V^T tiles by LDS-DMA; %d-row q tiles)",
+               "f16": "attn16_kernel<f16,QB=%d,WAVES=%d,MODE=1> (lazy-rescale online softmax; K/V^T tiles by LDS-DMA; %d-row q tiles)",
                "f32": "attn_kernel<float,QB=1> (exact-f32 MFMA 16x16x4, classic online softmax)",
                "f32x": "attn16_kernel<f16,QB=2,WAVES=8,MODE=1,X3> (split-f16: q / K / V^T / P as (hi, lo) f16 planes, three f16 MFMAs per product, "
                        "lazy-rescale online softmax, exact f32 row sums; K / V^T tiles by LDS-DMA; 256-row q tiles)"}
@@ -70,7 +70,10 @@ def kernel_name(dtype_name, n_q, n_k):
         return KERNEL_NAME[dtype_name]
     from omnivggt_official_amd import ops
     plan = ops.attn_plan(16, n_q, [n_k], DT[dtype_name])
-    name = KERNEL_NAME[dtype_name] % (min(plan["q_tile"] // 64, 8), plan["q_tile"])
+    qb, waves = {128: (2, 4), 256: (4, 4), 512: (4, 8)}[plan["q_tile"]]          # q tile = 16 x QB x WAVES rows (dispatch16 in ovg_attn.hip)
+    name = KERNEL_NAME[dtype_name] % (qb, waves, plan["q_tile"])
+    if plan["tail_q_tile"] and plan["splits"] > 1:                                    # key-split tail (ABI 9)
+        return name + "; rows %d.. of every head in a second launch cut into %d key ranges + merge" % (plan["main_rows"], plan["splits"])
     if plan["tail_q_tile"]:
         name += "; rows %d.. of every head in a second launch of %d-row tiles" % (plan["main_rows"], plan["tail_q_tile"])
     return name + (", split-KV x%d" % plan["splits"] if plan["splits"] > 1 else "")
@@ -190,8 +193,9 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the f32-mode cross-check of the timed outputs (N=1)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 8-view secondary measurement (N=1)")
     ap.add_argument("--torch-heads", action="store_true", help="with --e2e: run the DPT heads as f32 PyTorch modules instead of the HIP kernels")
-    ap.add_argument("--e2e-views", type=int, default=8, help="view count of the --e2e measurement")
-    ap.add_argument("--e2e", action="store_true", help="also time OmniVGGT.forward incl. the PyTorch heads (MIOpen JIT makes the first call slow)")
+    ap.add_argument("--e2e-views", type=int, default=0, help="view count of the end-to-end measurement (default: the timed view count, and 8 views next to the secondary)")
+    ap.add_argument("--e2e", action="store_true", help="(default since round 5; kept for old command lines) also time the whole OmniVGGT.forward")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end measurement (aggregator + camera head + both DPT heads; N = 1)")
     ap.add_argument("--attn-variant", type=int, default=0)
     ap.add_argument("--gemm-tile", type=int, default=0, help="force OVG_TILE_* on the block GEMMs (A/B runs)")
     ap.add_argument("--aux", action="store_true", help="depth + camera tokens on every view (BASELINE configs[2] with --views 16)")
@@ -437,11 +441,11 @@ def main():
         if args.dtype != "f32" and not args.no_parity:
             wd.stage("parity block (f32 mode of the same library on the same inputs)")
             result["parity"] = parity_block(agg, dev, args, sorted({8, S}) if not (args.views or args.aux or args.partial_aux) else [S])
-        if args.e2e:
-            # whole OmniVGGT.forward (aggregator + camera head + the two DPT heads) on the 8-view config; in the
-            # 16-bit modes the DPT heads run on the HIP kernels (heads_hip.py), `--torch-heads` forces PyTorch's
-            try:
-                Se = args.e2e_views
+        if not args.no_e2e:
+            # SURVEY 8d "report aggregator-only and end-to-end separately": the whole OmniVGGT.forward (aggregator + camera head + the two DPT
+            # heads, all on the HIP kernels; `--torch-heads` forces PyTorch's) with the step protocol of the headline -- 2 warm-ups, then
+            # timed forwards between synchronisations -- at the timed view count and, next to the secondary, at 8 views
+            def e2e_measure(Se, reps):
                 hd = "f32" if args.dtype in ("f32", "f32x") else args.dtype       # the split-f16 aggregator keeps the heads on the exact-f32 kernels
                 inp = synthetic_inputs(Se, dev, aux=args.aux)
                 idx = list(range(Se)) if args.aux else []
@@ -451,13 +455,19 @@ def main():
                 full()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                for _ in range(3):
+                for _ in range(reps):
                     full()
                 torch.cuda.synchronize()
-                ms = (time.perf_counter() - t1) / 3 * 1e3
-                result["e2e"] = {"views": Se, "frames_per_s": round(Se / ms * 1e3, 3), "ms_per_forward": round(ms, 3),
-                                 "dpt_heads": "pytorch-f32" if (args.torch_heads or (hd == "f32" and not model.hip_heads_f32)) else "hip-" + hd,
-                                 "camera_head": "pytorch-f32" if (args.torch_heads or (hd == "f32" and not model.hip_heads_f32)) else "hip-" + hd}
+                ms = (time.perf_counter() - t1) / reps * 1e3
+                torch_heads = args.torch_heads or (hd == "f32" and not model.hip_heads_f32)
+                return {"views": Se, "frames_per_s": round(Se / ms * 1e3, 3), "ms_per_forward": round(ms, 3), "forwards_timed": reps,
+                        "dpt_heads": "pytorch-f32" if torch_heads else "hip-" + hd, "camera_head": "pytorch-f32" if torch_heads else "hip-" + hd}
+            try:
+                wd.stage("end-to-end forward (aggregator + three heads)")
+                Se = args.e2e_views or S
+                result["e2e"] = e2e_measure(Se, 3 if Se > 16 else 5)
+                if "secondary" in result and not args.e2e_views and Se != 8:
+                    result["secondary"]["e2e"] = e2e_measure(8, 5)
             except Exception as e:  # never let the heads hide the hot-path number
                 result["e2e_error"] = repr(e)[:200]
         if not args.no_cpu_baseline:

@@ -219,7 +219,9 @@ typedef struct {
   const void* q_lo; void* out_lo;
   /* Telemetry of the speculative softmax (OVG_BF16 default kernels): optional DEVICE counter; every workgroup whose speculative pass
    * failed its verification and re-ran with the lazy-rescale body adds 1 (one atomic per such workgroup; nothing is written otherwise,
-   * the caller zeroes it). The result is exact either way -- the counter says how often the fast path did not pay. NULL = not counted. */
+   * the caller zeroes it). The counter says how often the fast path did not pay: a workgroup that re-ran returns the lazy-rescale result, one
+   * that did not returns the speculative pass's, accepted by its row-sum / finiteness check (and, for the order-pinned bf16 body, by the
+   * build-time disassembly guard of build.py). NULL = not counted. */
   uint32_t* fallback_count;
 } ovg_attn_params;
 int ovg_flash_attn(const ovg_attn_params*, void* stream);
@@ -526,8 +528,9 @@ int ovg_camera_head(const ovg_camera_head_params*, void* stream);
  *   tables[g, b*S+s] = adapt_w[g] emb[g, b*Sc+r] + adapt_b[g]   if s == index[r]        (exact-f32 MFMA)
  *                      adapt_b[g]                               otherwise (Linear of a zero row)
  * extrinsics [B,S,3,4] (world-to-camera), intrinsics [B,S,3,3] f32; index: DEVICE int32 [Sc], strictly the caller's
- * camera_gt_index (DISTINCT values in [0, S): the array is on the device, so the entry cannot reject it -- reads through an
- * out-of-range entry are clamped into [0, S) and its scatter is skipped, never an out-of-bounds access; duplicates are unsupported); pose_w [G*1024, 9] f32 row-major, pose_b [G*1024]; adapt_w [G,1024,1024] f32
+ * camera_gt_index (values in [0, S): the array is on the device, so the entry cannot reject it -- reads through an
+ * out-of-range entry are clamped into [0, S) and its scatter is skipped, never an out-of-bounds access; a view may appear more than once,
+ * as in the reference: the statistics run over the list as given and the duplicate entries scatter identical rows); pose_w [G*1024, 9] f32 row-major, pose_b [G*1024]; adapt_w [G,1024,1024] f32
  * (nn.Linear layout, 16-byte aligned), adapt_b [G,1024]; enc [B*Sc, 9] and emb [G, B*Sc, 1024] are caller-owned scratch
  * (NULL allowed when Sc == 0); tables [G, B*S, 1024] f32. Three launches (one when Sc == 0); nothing is read back.
  * ------------------------------------------------------------------ */

@@ -470,8 +470,9 @@ class ZeroAggregator(nn.Module):
         if idx_key not in pk:               # the index list reaches the device once per distinct list, not once per forward
             if min(idx_key[1]) < 0 or max(idx_key[1]) >= S:
                 raise IndexError("camera_gt_index out of range for %d views" % S)
-            if len(set(idx_key[1])) != len(idx_key[1]):
-                raise ValueError("camera_gt_index holds duplicate views (ovg_camera_tables scatters one table row per entry)")
+            # duplicate views are accepted like the reference accepts them (index_select + index assignment, omnivggt_aggregator.py:158-178):
+            # the normalisation statistics run over the list AS GIVEN (a duplicate counts twice in the mean camera distance), and the
+            # entries of one view describe one camera, so the table rows they scatter are byte-identical -- the concurrent writes are benign
             cached = [k for k in pk if isinstance(k, tuple) and k and k[0] == "cam_index"]
             if len(cached) >= 16:           # a long-lived process with ever-changing index lists: start over
                 for k in cached:

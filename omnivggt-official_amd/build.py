@@ -20,6 +20,56 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", 
 EXTRA_FLAGS = {"ovg_attn.hip": ["-fno-honor-nans"]}
 
 
+# attn16_kernel<bf16, QB, WAVES, MODE 0, OCC 2, VSUM false, DMA, X3 false>: the three launches of the bf16 plan (mangled-name fragment -> QB)
+PINNED_ATTENTION_KERNELS = {"IDF16bLi4ELi8ELi0ELi2ELb0ELi5ELb0E": 4, "IDF16bLi4ELi4ELi0ELi2ELb0ELi3ELb0E": 4, "IDF16bLi2ELi4ELi0ELi2ELb0ELi3ELb0E": 2}
+
+
+def check_pinned_attention_loops(asm_text):
+    """The order-pinned attention body (csrc/ovg_attn16_body_q*.inc: one `asm volatile` per MFMA / exp / convert / fragment read) is only
+    correct while hipcc allocates registers AROUND those statements without materialising copies: it inserts no hazard wait states for
+    inline asm, so a v_mov that builds a P fragment in front of the consuming asm MFMA, or a spilled accumulator, yields finite, plausible,
+    WRONG attention output that the kernel's own post-pass check (row sums, non-finite values) need not catch (round-4 advisor finding).
+    So the build itself disassembles what it just compiled and refuses to produce a library unless the hot loop of every shipped speculative
+    kernel holds exactly one tile's instructions and no v_mov / v_accvgpr / v_swap / scratch instruction. Returns the per-kernel counts."""
+    import re
+    kernels, name, body = {}, None, []
+    for line in asm_text.splitlines():
+        m = re.match(r"^(_ZN\S*attn16_kernel\S*):", line)
+        if m:
+            name, body = m.group(1), []
+            continue
+        if name is not None:
+            body.append(line)
+            if "s_endpgm" in line:
+                kernels[name], name = body, None
+    report = {}
+    for pat, qb in PINNED_ATTENTION_KERNELS.items():
+        hits = [k for k in kernels if pat in k]
+        if len(hits) != 1:
+            raise RuntimeError("pinned-attention check: kernel %s not found exactly once (%r)" % (pat, hits))
+        blocks, cur = [], []
+        for line in kernels[hits[0]]:
+            if re.match(r"^\.LBB", line):
+                blocks.append(cur)
+                cur = []
+            elif line.startswith("\t") and not line.strip().startswith((".", ";")):
+                cur.append(line.split()[0])
+        blocks.append(cur)
+        pinned = [b for b in blocks if sum("v_mfma" in i for i in b) == 18 * qb and b.count("v_exp_f32") == 16 * qb]
+        if len(pinned) != 1:
+            raise RuntimeError("pinned-attention check: %s has %d candidate hot loops (MFMA / exp counts per block: %r)"
+                               % (pat, len(pinned), [(sum("v_mfma" in i for i in b), b.count("v_exp_f32")) for b in blocks if any("v_mfma" in i for i in b)]))
+        hot = pinned[0]
+        if hot.count("v_cvt_pk_bf16_f32") != 8 * qb or hot.count("ds_read_b128") != 16:
+            raise RuntimeError("pinned-attention check: %s hot loop holds %d converts / %d fragment reads" % (pat, hot.count("v_cvt_pk_bf16_f32"), hot.count("ds_read_b128")))
+        bad = [i for i in hot if i.startswith(("v_mov", "v_accvgpr", "scratch_", "v_swap", "v_pk_mov"))]
+        if bad:
+            raise RuntimeError("pinned-attention check: hipcc materialised register copies / spills inside the pinned hot loop of %s: %r -- the "
+                               "bf16 attention results of this build are NOT trustworthy; rebuild with -DOVG_ATTN_PIPE_LOOP=0 or fix the body" % (pat, bad))
+        report[pat] = {"instructions": len(hot), "mfma": 18 * qb}
+    return report
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -76,11 +126,18 @@ def build(force=False, verbose=True):
             def cc(src):
                 obj = os.path.join(objdir, src.replace(".hip", ".o"))
                 cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+                if src == "ovg_attn.hip":
+                    cmd.insert(1, "-save-temps=obj")          # keeps the gfx950 assembly of THIS compile next to the object: checked below
                 r = subprocess.run(cmd, capture_output=True, text=True)
                 if r.returncode != 0:
                     raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
                 if verbose and r.stderr.strip():
                     sys.stderr.write(r.stderr)
+                if src == "ovg_attn.hip":
+                    asm = [f for f in os.listdir(objdir) if f.startswith("ovg_attn") and f.endswith(".s") and "gfx950" in f]
+                    if len(asm) != 1:
+                        raise RuntimeError("pinned-attention check: expected one gfx950 assembly file of ovg_attn.hip, found %r" % asm)
+                    check_pinned_attention_loops(open(os.path.join(objdir, asm[0])).read())
                 return obj
 
             try:

@@ -469,7 +469,18 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
     return rc != OVG_OK ? rc : launch_attn16<T, 2, 4, 0, 2, false, 3>(p, pl, st, pl.main_rows, p.nq);
   }
   switch (pl.variant) {
+    // the product's kernels: baseline (f32 parity path, in-process reference of the tests), the LDS-DMA kernels of the launch plan, and the
+    // forced-fallback form the tests use
     case 1: return launch_attn<T, 1>(p, st);
+    case 50: return launch_attn16<T, 4, 4, 0, 2, false, 3>(p, pl, st);
+    case 52: return launch_attn16<T, 4, 4, 1, 2, false, 3>(p, pl, st);
+    case 53: return launch_attn16<T, 4, 4, 2, 2, false, 3>(p, pl, st);
+    case 54: return launch_attn16<T, 2, 4, 0, 2, false, 3>(p, pl, st);
+    case 55: return launch_attn16<T, 2, 4, 1, 2, false, 3>(p, pl, st);
+    case 57: return launch_attn16<T, 4, 8, 0, 2, false, 5>(p, pl, st);
+#ifdef OVG_AB_VARIANTS
+    // A/B history (rounds 1-4; numbers in the logs under profiles/): compiled only into tools/probes/build_alt.py ab=-DOVG_AB_VARIANTS builds --
+    // co-compiled template variants perturb each other's register allocation, and variant 32 spills
     case 2: return launch_attn<T, 2>(p, st);
     case 6: return launch_attn16<T, 4, 4, 1>(p, pl, st);
     case 8: return launch_attn16<T, 2, 4, 1>(p, pl, st);
@@ -480,17 +491,16 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
     case 31: return launch_attn16<T, 4, 4, 0, 2, true>(p, pl, st);
     case 32: return launch_attn16<T, 2, 8, 0, 4>(p, pl, st);
     case 33: return launch_attn16<T, 4, 8, 0, 2>(p, pl, st);
-    case 50: return launch_attn16<T, 4, 4, 0, 2, false, 3>(p, pl, st);
     case 51: return launch_attn16<T, 4, 8, 0, 2, false, 3>(p, pl, st);
-    case 52: return launch_attn16<T, 4, 4, 1, 2, false, 3>(p, pl, st);
-    case 53: return launch_attn16<T, 4, 4, 2, 2, false, 3>(p, pl, st);
-    case 54: return launch_attn16<T, 2, 4, 0, 2, false, 3>(p, pl, st);
-    case 55: return launch_attn16<T, 2, 4, 1, 2, false, 3>(p, pl, st);
     case 56: return launch_attn16<T, 4, 4, 0, 2, false, 5>(p, pl, st);
-    case 57: return launch_attn16<T, 4, 8, 0, 2, false, 5>(p, pl, st);
     case 58: return launch_attn16<T, 4, 8, 0, 2, false, 7>(p, pl, st);
     case 59: return launch_attn16<T, 4, 8, 0, 2, false, 9>(p, pl, st);
     default: return OVG_E_ARG;
+#else
+    case 2: case 6: case 8: case 21: case 25: case 18: case 19: case 31: case 32: case 33: case 51: case 56: case 58: case 59:
+      return OVG_E_UNSUPPORTED;                      // A/B history: not in this build (OVG_AB_VARIANTS)
+    default: return OVG_E_ARG;
+#endif
   }
 }
 

@@ -601,7 +601,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params
         for (int r = 0; r < 4; ++r) bad = bad || attn16::nonfinite(o[qb][dt][r]);
     }
     if (__syncthreads_or(bad ? 1 : 0)) {
-      // telemetry (ovg_attn_params.fallback_count): one atomic per workgroup that pays the second pass; the result is exact either way
+      // telemetry (ovg_attn_params.fallback_count): one atomic per workgroup that pays the second pass. What the check above certifies is
+      // the ARITHMETIC of an accepted speculative pass (no overflowed row sum, nothing non-finite); that the order-pinned instruction stream
+      // itself is intact (no compiler copy inside an MFMA hazard window) is certified at BUILD time by build.check_pinned_attention_loops.
       if (p.fallback_count != nullptr && threadIdx.x == 0) atomicAdd(p.fallback_count, 1u);
       attn16::run_tiles<T, QB, WAVES, 0, VSUM, DMA>(p, lds, bh, q0, t0, nt, o, lacc, negm);
     }

@@ -186,7 +186,7 @@ bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 }  // namespace
 
 extern "C" int ovg_camera_tables(const ovg_camera_tables_params* p, void* stream) {
-  if (!p || !p->adapt_b || !p->tables || p->B <= 0 || p->S <= 0 || p->G <= 0 || p->Sc < 0 || p->Sc > p->S) return OVG_E_ARG;
+  if (!p || !p->adapt_b || !p->tables || p->B <= 0 || p->S <= 0 || p->G <= 0 || p->Sc < 0 || p->Sc > 8 * p->S) return OVG_E_ARG;   // Sc > S: a view listed more than once (accepted like the reference; the bound only stops nonsense)
   if (!al16(p->adapt_b) || !al16(p->tables)) return OVG_E_ARG;
   if (p->Sc > 0) {
     if (!p->extrinsics || !p->intrinsics || !p->index || !p->pose_w || !p->pose_b || !p->adapt_w || !p->enc || !p->emb) return OVG_E_ARG;

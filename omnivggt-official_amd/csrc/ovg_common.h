@@ -75,8 +75,11 @@ template <> OVG_DEV void store4<f16_t>(f16_t* dst, float a, float b, float c, fl
 
 // ---------------------------------------------------------------------------
 // Split-f16 mode (OVG_F16X2, "f32x"): x ~ hi + lo with hi = f16(x) (saturated at the largest finite f16) and lo = f16(x - hi),
-// stored in two f16 tensors of the same shape. |x - hi - lo| <= 2^-22 |x| while lo is a normal f16 (|x| >= 2^-3), <= 2^-25 absolute
-// below (lo subnormal; the f16 MFMA keeps subnormal inputs). Kernels take the mode as a `bool X3` template flag next to T = f16_t:
+// stored in two f16 tensors of the same shape. |x - hi - lo| <= 2^-22 |x| while lo is a normal f16 (|x| >= 2^-3), <= 2^-25 ABSOLUTE
+// below: for |x| < 2^-3 -- typical ViT weights (|w| ~ 0.01-0.05), most LayerNorm outputs -- lo is a SUBNORMAL f16 and the split is good to
+// ~2^-25 / |x| relative (1e-6 at |x| = 0.03, not 2^-22). The mode therefore relies on the f16 MFMA and the f32 <-> f16 conversions keeping
+// denormals (gfx950: they do; denormal mode is not touched anywhere in this library) -- gpu_selftest.py test_f32x feeds planes whose lo is
+// subnormal everywhere through ovg_linear on both tile sizes and requires their contribution in the result. Kernels take the mode as a `bool X3` template flag next to T = f16_t:
 // every contraction runs three MFMAs (lo*hi, hi*lo, hi*hi -- small terms first) into the same f32 accumulator.
 // ---------------------------------------------------------------------------
 OVG_DEV float f16_sat(float x) { return __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }

@@ -1004,7 +1004,11 @@ int launch_linear128_xp(const ovg_linear_params& p, hipStream_t st) {
 template <typename T>
 int launch_linear128(const ovg_linear_params& p, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
+#ifdef OVG_AB_VARIANTS
     if (p.tile & OVG_TILE_R02_EPILOGUE) return launch_linear128_xp<T, 1>(p, st);      // A/B flag: the r02 epilogue forms
+#else
+    if (p.tile & OVG_TILE_R02_EPILOGUE) return OVG_E_UNSUPPORTED;                      // A/B history: only in -DOVG_AB_VARIANTS builds
+#endif
   }
   return launch_linear128_xp<T, 0>(p, st);
 }
@@ -1031,10 +1035,23 @@ int launch_linear256(const ovg_linear_params& p, hipStream_t st, bool xp) {
     }
   }
 #endif
+#ifdef OVG_AB_VARIANTS
+  if (xp) {                                          // A/B flag: the r02 epilogue forms
+    switch (p.epilogue) {
+      case OVG_EPI_STORE: return p.out_f32 ? launch_linear256_one<T, OVG_EPI_STORE, true>(p, st) : launch_linear256_one<T, OVG_EPI_STORE, false, 1>(p, st);
+      case OVG_EPI_GELU: return launch_linear256_one<T, OVG_EPI_GELU, false, 1>(p, st);
+      case OVG_EPI_RES: return launch_linear256_one<T, OVG_EPI_RES, true, 1>(p, st);
+      case OVG_EPI_PATCH: return launch_linear256_one<T, OVG_EPI_PATCH, true>(p, st);
+      default: return OVG_E_ARG;
+    }
+  }
+#else
+  if (xp) return OVG_E_UNSUPPORTED;                  // A/B history: only in -DOVG_AB_VARIANTS builds
+#endif
   switch (p.epilogue) {
-    case OVG_EPI_STORE: return p.out_f32 ? launch_linear256_one<T, OVG_EPI_STORE, true>(p, st) : (xp ? launch_linear256_one<T, OVG_EPI_STORE, false, 1>(p, st) : launch_linear256_one<T, OVG_EPI_STORE, false>(p, st));
-    case OVG_EPI_GELU: return xp ? launch_linear256_one<T, OVG_EPI_GELU, false, 1>(p, st) : launch_linear256_one<T, OVG_EPI_GELU, false>(p, st);
-    case OVG_EPI_RES: return xp ? launch_linear256_one<T, OVG_EPI_RES, true, 1>(p, st) : launch_linear256_one<T, OVG_EPI_RES, true>(p, st);
+    case OVG_EPI_STORE: return p.out_f32 ? launch_linear256_one<T, OVG_EPI_STORE, true>(p, st) : launch_linear256_one<T, OVG_EPI_STORE, false>(p, st);
+    case OVG_EPI_GELU: return launch_linear256_one<T, OVG_EPI_GELU, false>(p, st);
+    case OVG_EPI_RES: return launch_linear256_one<T, OVG_EPI_RES, true>(p, st);
     case OVG_EPI_PATCH: return launch_linear256_one<T, OVG_EPI_PATCH, true>(p, st);
     default: return OVG_E_ARG;
   }

@@ -1,6 +1,6 @@
 """Interleaved A/B micro-benchmarks of the hot kernels on the bench shapes (GPU box tool).
 
-    python tests/bench_kernels.py attn [--views 8 16] [--variants 1 6 8 21 25] [--rounds 5]
+    python tests/bench_kernels.py attn [--views 8 16] [--variants 1 0 50] [--rounds 5]
     python tests/bench_kernels.py gemm [--views 8]
 
 Variants are interleaved inside one process (round-robin, median over rounds) on random
@@ -130,7 +130,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["attn", "gemm", "all"])
     ap.add_argument("--views", type=int, nargs="+", default=[8, 16])
-    ap.add_argument("--variants", type=int, nargs="+", default=[1, 6, 8, 21, 25], help="see dispatch16 in ovg_attn.hip")
+    ap.add_argument("--variants", type=int, nargs="+", default=[1, 0, 50], help="see dispatch16 in ovg_attn.hip (history variants need a -DOVG_AB_VARIANTS build)")
     ap.add_argument("--modes", nargs="+", default=["global", "frame"])
     ap.add_argument("--kv-splits", type=int, nargs="+", default=[1], help="attn: split-KV factors to compare (1 = off, 0 = library plan, 2..8 forced)")
     ap.add_argument("--rounds", type=int, default=5)

@@ -3,6 +3,7 @@ without a device, host-side camera math and heads vs the oracle."""
 import ctypes
 import json
 import os
+import sys
 import re
 import subprocess
 import tempfile
@@ -434,6 +435,38 @@ def test_traffic_json_tool_sums_the_dispatches_of_one_attention_and_stamps_the_d
     sys.path.insert(0, ROOT)
     import bench
     assert rec["attention_source_digest"] == bench.attention_source_digest()
+
+
+def test_checkpoint_rehearsal_key_check(tmp_path):
+    """tools/validate_checkpoint.py (round-4 review item 8): the host-side half -- a synthetic checkpoint with the reference's key set is
+    written and accepted; a file with a missing / renamed / reshaped tensor is reported, not loaded."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import validate_checkpoint as V
+    from safetensors.torch import load_file, save_file
+    path = V.write_synthetic(str(tmp_path / "synth.safetensors"), depth=1)
+    kc = V.check_keys(path, depth=1)
+    assert kc["ok"] and kc["keys_in_file"] == kc["keys_expected"] == 263
+    sd = load_file(path)
+    k0 = "aggregator.frame_blocks.0.attn.qkv.weight"
+    bad = dict(sd)
+    bad["aggregator.frame_blocks.0.attn.qkv_renamed.weight"] = bad.pop(k0)
+    bad["aggregator.camera_token"] = bad["aggregator.camera_token"][:, :1].contiguous()
+    save_file(bad, str(tmp_path / "bad.safetensors"))
+    kb = V.check_keys(str(tmp_path / "bad.safetensors"), depth=1)
+    assert not kb["ok"] and kb["missing"] == [k0] and kb["unexpected"] == ["aggregator.frame_blocks.0.attn.qkv_renamed.weight"]
+    assert [m[0] for m in kb["shape_mismatch"]] == ["aggregator.camera_token"]
+    assert not V.check_keys(path, depth=24)["ok"]                      # a depth-1 file is not the released model
+
+
+def test_split_f16_sentinel_survives_copy_and_pickle():
+    """lib.F32X is compared by identity everywhere; a deep copy of a model, a pickle round trip (torch.save / load,
+    multiprocessing) or a second construction must give back the same object."""
+    import copy
+    import pickle
+    assert copy.copy(L.F32X) is L.F32X and copy.deepcopy(L.F32X) is L.F32X
+    assert pickle.loads(pickle.dumps(L.F32X)) is L.F32X and type(L.F32X)() is L.F32X
+    assert copy.deepcopy({"compute_dtype": L.F32X})["compute_dtype"] is L.F32X
+    assert L.is_split(pickle.loads(pickle.dumps([L.F32X]))[0]) and L.dtype_code(copy.deepcopy(L.F32X)) == L.dtype_code(L.F32X)
 
 
 def test_attention_launch_plan_of_the_baseline_shapes():

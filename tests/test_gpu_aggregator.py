@@ -549,6 +549,26 @@ def test_full_depth_16_views_full_aux_vs_oracle_model_forward():
         torch.cuda.empty_cache()
 
 
+def test_duplicate_camera_indices_follow_the_reference(reduced):
+    """the reference tolerates a view listed twice in camera_gt_index (index_select + index assignment,
+    omnivggt_aggregator.py:158-178): the duplicate counts twice in the mean camera distance of normalize_extrinsics (:85-105) and the
+    scatter writes the same row twice. The HIP path used to refuse such a list; now it reproduces the reference (via the oracle)."""
+    sd, m = reduced
+    S, dgi, cgi = 3, [1], [0, 1, 2, 2]
+    inp = orc.synthetic_inputs(S)
+    with torch.no_grad():
+        ref, _ = orc.aggregator_forward(sd, inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi,
+                                        depth_layers=2, dino_layers=2)
+        ref_nodup, _ = orc.aggregator_forward(sd, inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, [0, 1, 2],
+                                              depth_layers=2, dino_layers=2)
+    assert common.max_rel(ref[1], ref_nodup[1]) > 1e-4            # the duplicate DOES change the result (scale of the translations)
+    toks, _ = run_agg(m, S, dgi, cgi)
+    for l in range(2):
+        err = common.max_rel(toks[l].cpu(), ref[l])
+        print("camera_gt_index [0, 1, 2, 2] layer %d max-rel vs oracle %.2e" % (l, err))
+        assert err <= F32_TOL
+
+
 def test_fp16_mode_with_outlier_activations():
     """fp16 range safety (SURVEY section 7 hard part; DINOv2-reg high-norm tokens, layers/vision_transformer.py:214-271):
     weights that reproduce the massive-activation pattern -- a few residual channels at |x| ~ 3e2..1e3 from the first DINOv2

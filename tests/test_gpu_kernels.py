@@ -73,10 +73,20 @@ def test_gemm256_kernels_every_epilogue_ragged_m():
     _assert_clean()
 
 
-def test_gemm256_r02_gelu_form_behind_the_knob():
-    """OVG_TILE_256X keeps the r02 erf_as GELU selectable for A/B runs (the default 16-bit GELU is the polynomial form)."""
-    st.test_gemm256(True, tile=L.TILE_256X, auto_is=False)
-    _assert_clean()
+def test_history_variants_are_not_in_the_product_library():
+    """Round-4 review, hygiene: the A/B history (r02 epilogue forms, attention variants of rounds 1-3) and the round-5 lab GEMM forms are compiled
+    only into tools/probes/build_alt.py builds (-DOVG_AB_VARIANTS / -DOVG_LAB_GEMM); the product library refuses them by name."""
+    import torch
+    from omnivggt_official_amd import ops
+    x = torch.zeros(512, 1024, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(1024, 1024, device="cuda", dtype=torch.bfloat16)
+    for tile in (L.TILE_256X, L.TILE_128X, L.TILE_256P, L.TILE_256M):
+        with pytest.raises(L.OvgError, match="UNSUPPORTED"):
+            ops.linear(x, w, None, torch.bfloat16, tile=tile)
+    q, k, vt = ops.alloc_qkv(16, 256, 256, torch.bfloat16, "cuda")
+    for variant in (6, 21, 33, 51, 59):
+        with pytest.raises(L.OvgError, match="UNSUPPORTED"):
+            ops.flash_attn(q, [(k, vt, 256)], 256, torch.bfloat16, variant=variant)
 
 
 def test_global_attention_at_bench_key_counts():

@@ -1,0 +1,151 @@
+"""Rehearsal for the day a real checkpoint exists: load `OmniVGGT.safetensors` the way the reference does
+(/root/reference/inference.py:321-325: load_file + load_state_dict(strict=True)), run the HIP model in every compute mode on the
+same synthetic views, and print what a maintainer needs before trusting a 16-bit mode on REAL weights:
+
+  * per-layer distance of each mode (split-f16, bf16, f16) from the exact-f32 mode of the same library -- max-rel (the SURVEY 8c metric)
+    and rms-rel of the aggregator's output tokens, layer by layer, plus the predictions (pose_enc / depth / world_points);
+  * max |activation| of the residual stream per layer (DINOv2-style massive activations are what breaks fp16);
+  * how many values of the f16 mode's outputs sit at the f16 saturation guard (65504) or are non-finite;
+  * `fallback_workgroups`: how often the speculative bf16 softmax had to re-run (0 on the synthetic weights).
+
+    python tools/validate_checkpoint.py checkpoints/OmniVGGT.safetensors [--views 2 8] [--aux] [--out report.json]
+    python tools/validate_checkpoint.py --synthetic /tmp/synth.safetensors [--depth 2]   # writes a checkpoint with the reference's key set
+                                                                                          # from the synthetic state dict and validates THAT
+    python tools/validate_checkpoint.py <file> --check-keys                               # host only: key set / shapes vs the manifest
+
+Needs a GPU except with --check-keys (which is what the CPU test runs). The f32 mode is the yardstick here, not the oracle: the oracle vs
+f32-mode distance is pinned by the test-suite (<= 1e-4); this tool measures what the REAL weights do to the faster modes."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def manifest():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_manifest.json")))
+
+
+def write_synthetic(path, depth=24, seed=2):
+    """A safetensors file with the reference's key set (reduced to `depth` blocks per stack when depth < 24) from weights.synthetic_state_dict."""
+    from safetensors.torch import save_file
+    from omnivggt_official_amd import weights
+    man = manifest() if depth >= 24 else weights.reduce_manifest(manifest(), depth, depth)
+    sd = weights.synthetic_state_dict(man, seed=seed)
+    save_file({k: v.contiguous() for k, v in sd.items()}, path)
+    return path
+
+
+def check_keys(path, depth=24):
+    """Host only: the file's keys / shapes against the manifest of the reference's state dict (1505 keys at full depth)."""
+    from safetensors import safe_open
+    from omnivggt_official_amd import weights
+    man = manifest() if depth >= 24 else weights.reduce_manifest(manifest(), depth, depth)
+    want = {k: tuple(v["shape"]) if isinstance(v, dict) else tuple(v) for k, v in man.items()}
+    with safe_open(path, framework="pt") as f:
+        have = {k: tuple(f.get_slice(k).get_shape()) for k in f.keys()}
+    missing = sorted(set(want) - set(have))
+    extra = sorted(set(have) - set(want))
+    wrong = sorted(k for k in set(want) & set(have) if want[k] != have[k])
+    return {"keys_in_file": len(have), "keys_expected": len(want), "missing": missing[:20], "unexpected": extra[:20],
+            "shape_mismatch": [(k, have[k], want[k]) for k in wrong[:20]], "ok": not (missing or extra or wrong)}
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    d = (a - b).abs()
+    return float(d.max() / b.abs().max().clamp(min=1e-30)), float(d.pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp(min=1e-30))
+
+
+def validate(path, views, aux, depth, device="cuda"):
+    import aggregator_oracle as orc
+    from omnivggt_official_amd import lib as L
+    from omnivggt_official_amd.model import OmniVGGT
+    L.require_gpu()
+    kw = {} if depth >= 24 else {"depth": depth, "dino_depth": depth}
+    model = OmniVGGT.from_safetensors(path, device=device, compute_dtype=torch.float32, **kw)
+    agg = model.aggregator
+    counter = agg.enable_fallback_counter(torch.device(device))
+    report = {"checkpoint": path, "views": {}}
+    modes = [("f32", torch.float32), ("f32x", L.F32X), ("bf16", torch.bfloat16), ("f16", torch.float16)]
+    keys = ("pose_enc", "depth", "depth_conf", "world_points", "world_points_conf")
+    for S in views:
+        inp = {k: v.to(device) for k, v in orc.synthetic_inputs(S).items()}
+        dgi = list(range(0, S, 2)) if aux else []
+        cgi = list(range(S)) if aux else []
+        ref_tok, ref_pred, rows = None, None, {}
+        for name, dt in modes:
+            model.set_compute_dtype(dt)
+            counter.zero_()
+            with torch.no_grad():
+                pred = model(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
+                toks, _ = agg(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
+            torch.cuda.synchronize()
+            fb = int(counter.item())
+            toks = [t.float().cpu() for t in toks]
+            pred = {k: pred[k].float().cpu() for k in keys}
+            entry = {"fallback_workgroups": fb, "nonfinite_tokens": int(sum((~torch.isfinite(t)).sum() for t in toks)),
+                     "nonfinite_predictions": int(sum((~torch.isfinite(v)).sum() for v in pred.values())),
+                     "max_abs_residual_per_layer": [round(float(t.abs().max()), 3) for t in toks]}
+            if name == "f16":
+                entry["values_at_f16_guard"] = int(sum((t.abs() >= 65504.0).sum() for t in toks))
+            if ref_tok is None:
+                ref_tok, ref_pred = toks, pred
+            else:
+                per_layer = [rel(t, r) for t, r in zip(toks, ref_tok)]
+                entry["tokens_max_rel_per_layer"] = ["%.2e" % e[0] for e in per_layer]
+                entry["tokens_rms_rel_per_layer"] = ["%.2e" % e[1] for e in per_layer]
+                entry["tokens_max_rel_worst"] = max(e[0] for e in per_layer)
+                entry["predictions_max_rel"] = {k: float("%.3e" % rel(pred[k], ref_pred[k])[0]) for k in keys}
+            rows[name] = entry
+            worst = entry.get("tokens_max_rel_worst")
+            print("S=%d %-4s fallback workgroups %d, non-finite %d / %d, max |x| %.1f%s%s" % (
+                S, name, fb, entry["nonfinite_tokens"], entry["nonfinite_predictions"], max(entry["max_abs_residual_per_layer"]),
+                "" if worst is None else ", worst layer vs f32 mode: max-rel %.2e" % worst,
+                "" if name != "f16" else ", values at the f16 guard: %d" % entry["values_at_f16_guard"]), flush=True)
+            if worst is not None:
+                print("        per layer max-rel: " + " ".join(entry["tokens_max_rel_per_layer"]))
+                print("        predictions max-rel: " + json.dumps(entry["predictions_max_rel"]))
+        report["views"][str(S)] = rows
+    model.set_compute_dtype(torch.float32)
+    return report
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("checkpoint", nargs="?", help="safetensors file with the reference's key set (checkpoints/OmniVGGT.safetensors)")
+    ap.add_argument("--synthetic", metavar="PATH", help="first write a synthetic checkpoint with the reference's key set to PATH, then validate it")
+    ap.add_argument("--depth", type=int, default=24, help="blocks per stack of the checkpoint (24 = the released model; smaller only with --synthetic)")
+    ap.add_argument("--views", type=int, nargs="+", default=[2, 8])
+    ap.add_argument("--aux", action="store_true", help="depth on every other view + cameras on every view")
+    ap.add_argument("--check-keys", action="store_true", help="host only: compare the file's key set / shapes with the reference manifest and exit")
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    path = args.checkpoint
+    if args.synthetic:
+        path = write_synthetic(args.synthetic, args.depth)
+        print("wrote synthetic checkpoint", path)
+    if not path:
+        ap.error("give a checkpoint or --synthetic PATH")
+    kc = check_keys(path, args.depth)
+    print("key set: %d in the file, %d expected, missing %d, unexpected %d, shape mismatches %d -> %s"
+          % (kc["keys_in_file"], kc["keys_expected"], len(kc["missing"]), len(kc["unexpected"]), len(kc["shape_mismatch"]), "OK" if kc["ok"] else "MISMATCH"))
+    if not kc["ok"]:
+        print(json.dumps({k: kc[k] for k in ("missing", "unexpected", "shape_mismatch")}, indent=1))
+    if args.check_keys:
+        return 0 if kc["ok"] else 1
+    report = validate(path, args.views, args.aux, args.depth)
+    report["key_check"] = kc
+    if args.out:
+        json.dump(report, open(args.out, "w"), indent=1)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -78,6 +78,7 @@ for stage in "$@"; do
       done 2>&1 | tee "$O/bench_view_sweep.txt" ;;
     attn_st)    (timeout 900 python tests/gpu_selftest.py --only attn,attn_big,lse_merge,fallback 2>&1 | grep -v amdgpu.ids | grep -E "FAIL|SELFTEST|Error|error|Traceback|raise|fault|core|keytail|\(attn" | head -80) | tee "$O/attn_selftest.txt" ;;
     attn_ab8)   (timeout 900 python tests/bench_kernels.py attn --modes global --views ${OVG_AB_VIEWS:-8 9 10 12 13} --variants ${OVG_AB_VARIANTS:-0 50} --kv-splits ${OVG_AB_SPLITS:-0 1} --rounds 4 --target-ms 30 2>&1 | grep -v amdgpu.ids | tail -40) | tee "$O/attn_keytail_ab.txt" ;;
+    ckpt)       (timeout 1500 python tools/validate_checkpoint.py --synthetic /tmp/ovg_synth_ckpt.safetensors --views 2 8 --aux --out "$O/checkpoint_rehearsal.json" 2>&1 | grep -v amdgpu.ids | tail -60) | tee "$O/checkpoint_rehearsal.txt"; rm -f /tmp/ovg_synth_ckpt.safetensors ;;
     gemm_m)     (timeout 400 python tests/gpu_selftest.py --only gemm256m ${OVG_SELFTEST_ARGS:---quick} 2>&1 | grep -v amdgpu.ids | grep -E "FAIL|SELFTEST|Error|error|Traceback|raise|fault|core|gemm256m:" | head -60) | tee "$O/gemm256m_selftest.txt" ;;
     gemm_p)     (timeout 400 python tests/gpu_selftest.py --only gemm256p ${OVG_SELFTEST_ARGS:---quick} 2>&1 | grep -v amdgpu.ids | grep -E "FAIL|SELFTEST|Error|error|Traceback|raise|fault|core|gemm256p:" | head -60) | tee "$O/gemm256p_selftest.txt" ;;
     gemm_tl)    (timeout 900 python tools/probes/gemm_timeline.py ${OVG_TL_ARGS:-} 2>&1 | grep -v amdgpu.ids | tail -80) | tee "$O/gemm_timeline.txt" ;;
