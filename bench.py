@@ -315,7 +315,8 @@ def main():
         form = ""
         if shard is not None:
             from omnivggt_official_amd.sharding import head_groups
-            ng = len(head_groups(16 // world, world, n_local * P_TOK)) if 16 % world == 0 else 1
+            ex_now = next(iter(shard._executors.values()), None)
+            ng = len(head_groups(16 // world, world, n_local * P_TOK, cus=int(getattr(ex_now, "cus", 0)) or 256)) if 16 % world == 0 else 1
             form = ", " + {"heads": "head-parallel all-to-all, %s" % ("2 pipelined head groups" if ng == 2 else "1 head group per rank"),
                            "allgather": "K/V all-gather, local keys first + log-sum-exp merge"}[shard.last_mode]
         res = {
@@ -362,9 +363,13 @@ def main():
         comp_ms = (time.perf_counter() - t0) / steps * 1e3
         shard.skip_comm = False
         ex_ms, comp_ms = reduce_max([ex_ms, comp_ms])
-        return {"exchange_form": shard.last_mode, "comm_ms_per_layer": round(ex_ms / agg.depth, 4), "comm_ms_per_step_unoverlapped": round(ex_ms, 3),
-                "compute_only_ms_per_step": round(comp_ms, 3), "exposed_comm_ms": round(step_ms - comp_ms, 3),
-                "hidden_fraction": round(1.0 - max(step_ms - comp_ms, 0.0) / max(ex_ms, 1e-9), 3)}
+        rep = {"exchange_form": shard.last_mode, "comm_ms_per_layer": round(ex_ms / agg.depth, 4), "comm_ms_per_step_unoverlapped": round(ex_ms, 3),
+               "compute_only_ms_per_step": round(comp_ms, 3), "exposed_comm_ms": round(step_ms - comp_ms, 3),
+               "hidden_fraction": round(1.0 - max(step_ms - comp_ms, 0.0) / max(ex_ms, 1e-9), 3)}
+        # what the launch plans of the global attention were told about the chip they share with RCCL (sharding.available_cus):
+        # backend, rccl_channels / NCCL_MAX_NCHANNELS, attention_plan_cus of device_cus
+        rep.update(shard.comm_report(torch.cuda.get_device_properties(dev).multi_processor_count))
+        return rep
 
     S = args.views or 64
     if shard is not None:

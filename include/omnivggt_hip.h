@@ -223,6 +223,11 @@ typedef struct {
    * that did not returns the speculative pass's, accepted by its row-sum / finiteness check (and, for the order-pinned bf16 body, by the
    * build-time disassembly guard of build.py). NULL = not counted. */
   uint32_t* fallback_count;
+  /* ABI 9: CUs the launch plan may count on (0 = all the device has). One process per GPU shares its chip with RCCL's kernels in the
+   * sharded run -- every channel of an exchange in flight holds a workgroup slot while the attention launch it overlaps runs -- so the q tile,
+   * the tail split and the split-KV factor are planned for `cus` CUs instead of quantising against slots that are not there. ovg_attn_plan
+   * answers for the same value. */
+  int cus;
 } ovg_attn_params;
 int ovg_flash_attn(const ovg_attn_params*, void* stream);
 
@@ -302,6 +307,7 @@ typedef struct {
   /* OVG_F16X2: lo planes of the six scratch tensors (same sizes as their hi tensors; ovg_block_workspace_bytes reports the size of ONE plane) */
   void* ws_xn_lo; void* ws_q_lo; void* ws_k_lo; void* ws_vt_lo; void* ws_attn_lo; void* ws_hid_lo;
   uint32_t* attn_fallback_count;   /* forwarded to ovg_attn_params.fallback_count of the block's attention launch (NULL = not counted) */
+  int attn_cus;                    /* forwarded to ovg_attn_params.cus (0 = the whole device) */
 } ovg_block_params;
 /* whole block */
 int ovg_block_forward(const ovg_block_params*, void* stream);

@@ -106,14 +106,14 @@ class Workspace:
         self.q, self.k, self.vt = ops.alloc_qkv(self.BH, rows, rows, dtype, device)
         self.device, self._split = device, {}
 
-    def split_ws(self, variant=0, kv_splits=0):
+    def split_ws(self, variant=0, kv_splits=0, cus=0):
         """(ws_part, ws_lse) for this shape's self-attention launch if ovg_attn_plan -- asked with the SAME variant and the same
         forced / automatic split factor the launch will carry -- cuts it along the keys (launches that would leave CUs idle:
         8-view global attention = 688 workgroups on 512 slots), else (None, None). The buffers' sizes travel with the pointers
         (ovg_attn_params.ws_part_bytes / ws_lse_bytes), so a plan / launch mismatch is an error code, not an overrun."""
-        key = (variant, kv_splits)
+        key = (variant, kv_splits, cus)
         if key not in self._split:
-            plan = (ops.attn_plan(self.BH, self.seq, [self.seq], self.dtype, variant, kv_splits, nq_pad=self.q.shape[1])
+            plan = (ops.attn_plan(self.BH, self.seq, [self.seq], self.dtype, variant, kv_splits, nq_pad=self.q.shape[1], cus=cus)
                     if (self.dtype in (torch.bfloat16, torch.float16) and kv_splits != 1) else {"splits": 1})
             self._split[key] = ops.alloc_split_ws(plan, self.device)
         return self._split[key]
@@ -186,8 +186,9 @@ class BlockRunner:
         p.gemm_tile = int(getattr(self.knobs, "gemm_tile", 0))
         p.attn_kv_splits = int(getattr(self.knobs, "attn_kv_splits", 0))
         p.attn_fallback_count = L.ptr(getattr(self.knobs, "fallback_counter", None))
+        p.attn_cus = int(getattr(self.knobs, "attn_cus", 0))
         if p.attn_kv_splits != 1 and hasattr(ws, "split_ws"):
-            part, lse = ws.split_ws(p.attn_variant, p.attn_kv_splits)
+            part, lse = ws.split_ws(p.attn_variant, p.attn_kv_splits, p.attn_cus)
             p.ws_attn_part, p.ws_attn_lse = L.ptr(part), L.ptr(lse)
             p.ws_attn_part_bytes, p.ws_attn_lse_bytes = ops.nbytes(part), ops.nbytes(lse)
         return p
@@ -249,6 +250,7 @@ class ZeroAggregator(nn.Module):
         self.attn_variant = 0       # ovg_attn_params.variant of every attention call (0 = library default); read per call
         self.gemm_tile = 0          # OVG_TILE_* forced on the block GEMMs (tests); 0 = shape heuristic
         self.attn_kv_splits = 0     # ovg_attn_params.kv_splits: 0 = library decides per launch, 1 = never split
+        self.attn_cus = 0           # ovg_attn_params.cus: CUs the attention launch plans may count on (0 = the whole device; ViewSharding sets it)
         self.max_workspaces = 4     # scratch shapes kept alive (frame + global of the two most recent geometries)
         self.shard = None           # set by sharding.ViewSharding for the multi-GPU path
         self.fallback_counter = None    # enable_fallback_counter(): device int32 the attention launches count their re-run workgroups into

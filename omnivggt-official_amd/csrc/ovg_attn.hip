@@ -303,7 +303,7 @@ Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
   if (v == 71) v = 57;            // A/B tool: the 512-row kernel with its tail split (dispatch16)
   if (v == 72) v = 50;            // A/B tool: the 256-row kernel with a tail split (dispatch16)
   if (v == 73) v = 50;            // A/B tool: the 256-row kernel with a key-split tail (dispatch16)
-  const int cus = cu_count_attn();
+  const int cus = (p.cus > 0 && p.cus < cu_count_attn()) ? p.cus : cu_count_attn();   // ovg_attn_params.cus: what RCCL leaves us in the sharded run
   const int64_t units512 = p.BH * ((p.nq + 511) / 512);
   // 512-row tiles (8 waves, one workgroup per CU, barrier every 2 tiles) from ~2.5 rounds of them on: 16 views +5.9 %, 64 views +3 %
   // over the 256-row kernel; below that the coarser tiles quantise worse than they gain (8 views: -17 %)
@@ -527,7 +527,7 @@ extern "C" int ovg_flash_attn(const ovg_attn_params* p, void* stream) {
   if ((reinterpret_cast<uintptr_t>(p->q) | reinterpret_cast<uintptr_t>(p->out)) & 15) return OVG_E_ARG;
   if (p->lse && (reinterpret_cast<uintptr_t>(p->lse) & 3)) return OVG_E_ARG;
   if (p->fallback_count && (reinterpret_cast<uintptr_t>(p->fallback_count) & 3)) return OVG_E_ARG;
-  if (p->kv_splits < 0 || p->kv_splits > OVG_MAX_SEG) return OVG_E_ARG;
+  if (p->kv_splits < 0 || p->kv_splits > OVG_MAX_SEG || p->cus < 0) return OVG_E_ARG;
   if ((p->ws_part && (reinterpret_cast<uintptr_t>(p->ws_part) & 15)) || (p->ws_lse && (reinterpret_cast<uintptr_t>(p->ws_lse) & 3))) return OVG_E_ARG;
   if (p->kv_splits > 1 && (p->dtype == OVG_F32 || p->variant == 1 || p->variant == 2)) return OVG_E_UNSUPPORTED;   // the baseline kernel never splits
   if (p->ldo % 4 || p->kv_heads < 0 || p->out_bh_stride < 0 || (p->out_bh_stride > 0 && (p->ldo < OVG_D || p->out_bh_stride % 4))) return OVG_E_ARG;

@@ -60,6 +60,7 @@ int run_epilogue(const ovg_block_params* p, void* st) {
   a.kv_splits = p->attn_kv_splits; a.ws_part = p->ws_attn_part; a.ws_lse = p->ws_attn_lse;
   a.ws_part_bytes = p->ws_attn_part_bytes; a.ws_lse_bytes = p->ws_attn_lse_bytes;
   a.fallback_count = p->attn_fallback_count;
+  a.cus = p->attn_cus;
   a.q_lo = p->ws_q_lo; a.out_lo = p->ws_attn_lo;
   if (p->ev_attn_start) (void)hipEventRecord(static_cast<hipEvent_t>(p->ev_attn_start), static_cast<hipStream_t>(st));
   rc = ovg_flash_attn(&a, st);

@@ -55,7 +55,7 @@ class AttnParams(C.Structure):
     _fields_ = [("q", vp), ("nq", i64), ("nq_pad", i64), ("seg", KvSegment * OVG_MAX_SEG), ("nseg", i32),
                 ("out", vp), ("ldo", i64), ("BH", i64), ("dtype", i32), ("variant", i32),
                 ("kv_heads", i32), ("out_bh_stride", i64), ("lse", vp), ("kv_splits", i32), ("ws_part", vp), ("ws_lse", vp),
-                ("ws_part_bytes", i64), ("ws_lse_bytes", i64), ("q_lo", vp), ("out_lo", vp), ("fallback_count", vp)]
+                ("ws_part_bytes", i64), ("ws_lse_bytes", i64), ("q_lo", vp), ("out_lo", vp), ("fallback_count", vp), ("cus", i32)]
 
 
 class AttnPlanOut(C.Structure):
@@ -88,7 +88,7 @@ class BlockParams(C.Structure):
                 ("skip_attention", i32), ("gemm_tile", i32), ("ws_attn_part", vp), ("ws_attn_lse", vp), ("attn_kv_splits", i32),
                 ("ws_attn_part_bytes", i64), ("ws_attn_lse_bytes", i64),
                 ("ws_xn_lo", vp), ("ws_q_lo", vp), ("ws_k_lo", vp), ("ws_vt_lo", vp), ("ws_attn_lo", vp), ("ws_hid_lo", vp),
-                ("attn_fallback_count", vp)]
+                ("attn_fallback_count", vp), ("attn_cus", i32)]
 
 
 class BlockWorkspace(C.Structure):

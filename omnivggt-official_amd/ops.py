@@ -168,14 +168,14 @@ def qkv(x, w, bias, seq, dtype, q, k, vt, qk_norm=None, rope=None, tokens_per_vi
     L.call("ovg_qkv", p, _stream())
 
 
-def attn_plan(BH, nq, nks, dtype, variant=0, kv_splits=0, nq_pad=None):
+def attn_plan(BH, nq, nks, dtype, variant=0, kv_splits=0, nq_pad=None, cus=0):
     """How ovg_flash_attn would run this shape (host-only query): dict(splits, q_tile, part_bytes, lse_bytes, main_rows, tail_q_tile).
     nq_pad: row count of the q buffer the call will use (default: nq padded to 64); the partial buffers are sized with it."""
     p = L.AttnParams()
     p.nq, p.nq_pad, p.BH, p.nseg = nq, (pad_to(nq, KV_TILE) if nq_pad is None else nq_pad), BH, len(nks)
     for i, nk in enumerate(nks):
         p.seg[i].nk = nk
-    p.dtype, p.variant, p.kv_splits = L.dtype_code(dtype), variant, kv_splits
+    p.dtype, p.variant, p.kv_splits, p.cus = L.dtype_code(dtype), variant, kv_splits, cus
     out = L.AttnPlanOut()
     L.check(L.load().ovg_attn_plan(L.C.byref(p), L.C.byref(out)), "ovg_attn_plan")
     return {"splits": out.splits, "q_tile": out.q_tile, "part_bytes": out.part_bytes, "lse_bytes": out.lse_bytes,
@@ -190,7 +190,7 @@ def alloc_split_ws(plan, device):
             torch.empty(plan["lse_bytes"] // 4, device=device, dtype=torch.float32))
 
 
-def flash_attn(q, segments, nq, dtype, out=None, variant=0, kv_heads=0, head_major=False, lse=None, kv_splits=0, split_ws=None, fallback_count=None):
+def flash_attn(q, segments, nq, dtype, out=None, variant=0, kv_heads=0, head_major=False, lse=None, kv_splits=0, split_ws=None, fallback_count=None, cus=0):
     """q [BH,nq_pad,64]; segments: list of (k [BHkv,nk_pad,64], vt [BHkv,64,nk_pad], nk).
     Returns out [B*nq, 1024] token-major, or with head_major=True out [BH, nq_pad, 64].
     kv_heads > 0: the segments hold kv_heads heads and batch entry bh attends to head bh % kv_heads
@@ -225,7 +225,7 @@ def flash_attn(q, segments, nq, dtype, out=None, variant=0, kv_heads=0, head_maj
         if lse.dtype != torch.float32 or tuple(lse.shape) != (BH, q.shape[1]) or not lse.is_contiguous():
             raise L.OvgError("lse must be a contiguous f32 [BH, nq_pad] tensor")
         p.lse = L.ptr(lse)
-    p.kv_splits = kv_splits
+    p.kv_splits, p.cus = kv_splits, cus            # cus: CUs the launch plan may count on (0 = all; sharded runs leave some to RCCL)
     if split_ws is not None and split_ws[0] is not None:
         _chk_dev(*split_ws)
         p.ws_part, p.ws_lse = L.ptr(split_ws[0]), L.ptr(split_ws[1])

@@ -22,6 +22,8 @@ Two exchange forms, both overlapped with compute (ViewSharding(mode=...)):
     send chunk is contiguous and the received K / V^T chunks are used in place as `world` kernel
     segments), attention runs over (source rank, head) batch entries (`kv_heads`), one all-to-all
     returns the head-major outputs, ovg_heads_to_tokens restores the token-major layout.
+    q, k and v^T of a head group travel as ONE grouped RCCL launch (batch_isend_irecv: 3 x (world - 1) sends + receives in a single
+    ncclGroup) and the attention launch plans are told how many CUs RCCL's channels leave them (available_cus -> ovg_attn_params.cus).
     Pipelined in HEAD GROUPS where that pays (head_groups(): 2 groups while each group's attention
     launch still covers >= 2 rounds of the chip's 512 workgroup slots -- 2 or 4 ranks at 64 views;
     at 8 ranks x 8 views a rank owns 2 heads, a per-head launch would be 344 workgroups and the
@@ -78,16 +80,36 @@ def _parity_mode(agg):
     return dt is torch.float32 or ops.L.is_split(dt)
 
 
-def head_groups(heads_per_rank, world=1, n_tokens=None):
+DEVICE_CUS = 256          # MI355X; head_groups / reserved_cus take the real count where a device is visible
+
+
+def rccl_channels():
+    """Channels (= workgroups, one CU each while the kernel runs) an RCCL exchange may occupy: NCCL_MAX_NCHANNELS when the job sets
+    it, else RCCL's own ceiling of 32 on this class of GPU. The exchange of the sharded forward is in flight DURING the attention
+    launches it overlaps, so their launch plans must not count on those CUs."""
+    import os
+    v = os.environ.get("NCCL_MAX_NCHANNELS", "")
+    return max(1, int(v)) if v.isdigit() else 32
+
+
+def available_cus(world, device_cus=DEVICE_CUS):
+    """CUs the attention launch plans count on (ovg_attn_params.cus): all of them on one GPU, device minus RCCL's channels in a
+    sharded run (never less than three quarters of the chip: a mis-set environment must not cripple the plan)."""
+    if world <= 1:
+        return device_cus
+    return max(device_cus - rccl_channels(), (3 * device_cus) // 4)
+
+
+def head_groups(heads_per_rank, world=1, n_tokens=None, cus=DEVICE_CUS):
     """Pipeline groups of the heads form: [(first head, count)] inside a rank's head range. Two groups (exchange of
     group 1 under attention of group 0) only while EACH group's attention launch still fills the chip: its
-    world * heads * ceil(n / 256) workgroups must cover >= 2 rounds of the 512 resident slots -- at 8 ranks x 8 views a
+    world * heads * ceil(n / 256) workgroups must cover >= 2 rounds of the 2 x `cus` resident slots -- at 8 ranks x 8 views a
     rank owns 2 heads and one launch per head would be 344 workgroups (0.67 of a round): the quantisation loss would
     dwarf the ~0.15 ms of exchange it hides, so that case stays one group (split-KV keeps its single launch even)."""
     if heads_per_rank < 2:
         return [(0, heads_per_rank)]
     half = heads_per_rank // 2
-    if n_tokens is not None and world * half * ((n_tokens + 255) // 256) < 1024:
+    if n_tokens is not None and world * half * ((n_tokens + 255) // 256) < 4 * cus:
         return [(0, heads_per_rank)]
     return [(0, half), (half, heads_per_rank - half)]
 
@@ -100,6 +122,7 @@ class HipExecutor:
         self.agg, self.device = agg, device
         self.pk = agg.pack(device)
         self._cache = {}
+        self.cus = 0        # ovg_attn_params.cus of the global-attention launches (0 = whole device); ViewSharding.executor sets it for RCCL runs
 
     def _stream(self):
         return torch.cuda.current_stream().cuda_stream
@@ -174,16 +197,17 @@ class HipExecutor:
         nk = sum(s[2] for s in segs)
         dt, variant = self.agg.compute_dtype, self.agg.attn_variant
         splits = getattr(self.agg, "attn_kv_splits", 0)
+        cus = self.cus                                               # CUs left to the attention plans beside RCCL's channels (ViewSharding sets it)
         split_ws = None
         if splits != 1 and dt in (torch.bfloat16, torch.float16):     # per-rank launches are the ones that quantise badly (688 workgroups on 512 slots)
-            key = ("split", q.shape[0], n, q.shape[1], tuple(s[2] for s in segs), variant, splits)
+            key = ("split", q.shape[0], n, q.shape[1], tuple(s[2] for s in segs), variant, splits, cus)
             split_ws = self._cached(key, lambda: ops.alloc_split_ws(
-                ops.attn_plan(q.shape[0], n, [s[2] for s in segs], dt, variant, splits, nq_pad=q.shape[1]), self.device))
+                ops.attn_plan(q.shape[0], n, [s[2] for s in segs], dt, variant, splits, nq_pad=q.shape[1], cus=cus), self.device))
         ev = self.agg.next_attention_events(4.0 * q.shape[0] * n * nk * 64)
         if ev is not None:
             ev[0].record()
         ops.flash_attn(q, segs, n, dt, out=out, variant=variant, kv_heads=kv_heads, head_major=head_major, lse=lse,
-                       kv_splits=splits, split_ws=split_ws, fallback_count=getattr(self.agg, "fallback_counter", None))
+                       kv_splits=splits, split_ws=split_ws, fallback_count=getattr(self.agg, "fallback_counter", None), cus=cus)
         if ev is not None:
             ev[1].record()
         return out
@@ -218,12 +242,12 @@ class HipExecutor:
             pad = ws_g.q.shape[1]
             dt, dev = ws_g.q.dtype, self.device
             groups = []
-            for h0, gs in head_groups(16 // world, world, n_local * P):
+            for h0, gs in head_groups(16 // world, world, n_local * P, cus=self.cus or DEVICE_CUS):
                 groups.append({"h0": h0, "gs": gs,
                                "q": torch.zeros(world, gs, pad, 64, device=dev, dtype=dt), "k": torch.zeros(world, gs, pad, 64, device=dev, dtype=dt),
                                "vt": torch.zeros(world, gs, 64, pad, device=dev, dtype=dt), "o": torch.zeros(world, gs, pad, 64, device=dev, dtype=dt)})
             return ws_f, ws_g, {"groups": groups, "o_back": torch.zeros_like(ws_g.q)}
-        return self._cached(("heads", n_local, P, world), make)
+        return self._cached(("heads", n_local, P, world, self.cus), make)
 
     def global_qkv(self, i, ws, x_in, x_out):
         self._prologue(i, ws, x_in, x_out, 0)
@@ -250,10 +274,13 @@ class ViewSharding:
     K/V all-gather), "heads" or "allgather".  skip_comm (bench.py only): issue no collective at all -- the step then
     runs the same kernels on whatever the exchange buffers hold, which times the compute of a sharded step alone."""
 
-    def __init__(self, group=None, executor_factory=None, gather_output=False, mode="auto"):
+    def __init__(self, group=None, executor_factory=None, gather_output=False, mode="auto", reserve_cus="auto"):
+        """reserve_cus: plan the global-attention launches for the CUs RCCL's channels leave free (available_cus) -- "auto": when the
+        backend is RCCL (its kernels share the GPU with the launches they overlap), True / False: always / never (tests)."""
         if mode not in ("auto", "heads", "allgather"):
             raise ValueError("mode must be auto, heads or allgather")
         self.mode = mode
+        self.reserve_cus = reserve_cus
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
@@ -270,8 +297,21 @@ class ViewSharding:
         key = (id(agg), str(device), getattr(agg, "compute_dtype", None), id(getattr(agg, "_packed", None)))
         if key not in self._executors:
             self._executors.clear()                      # a re-pack / dtype change invalidates the old executor's buffers
-            self._executors[key] = self.executor_factory(agg, device)
+            ex = self.executor_factory(agg, device)
+            reserve = self._nccl() if self.reserve_cus == "auto" else bool(self.reserve_cus)
+            if reserve and self.world > 1 and hasattr(ex, "cus"):
+                dev_cus = (torch.cuda.get_device_properties(device).multi_processor_count
+                           if (torch.cuda.is_available() and str(device).startswith("cuda")) else DEVICE_CUS)
+                ex.cus = available_cus(self.world, dev_cus)
+            self._executors[key] = ex
         return self._executors[key]
+
+    def comm_report(self, device_cus=DEVICE_CUS):
+        """What bench.py prints under `comm`: backend, RCCL's channel ceiling and the CU budget the attention plans were given."""
+        import os
+        ex = next(iter(self._executors.values()), None)
+        return {"backend": dist.get_backend(self.group), "rccl_channels": rccl_channels(), "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"),
+                "attention_plan_cus": int(getattr(ex, "cus", 0)) or device_cus, "device_cus": device_cus}
 
     # ---- collectives: RCCL on device tensors; with a host backend (gloo) device tensors are staged through the
     #      host, so the same control flow also runs where RCCL cannot (tests, several ranks sharing one GPU) -------
@@ -307,6 +347,39 @@ class ViewSharding:
             return self._Done()
         w = dist.all_to_all(outs, ins, group=self.group, async_op=async_op)
         return w if async_op else self._Done()
+
+    def _exchange_many(self, pairs, async_op=False):
+        """Several list-form all-to-alls as ONE grouped RCCL launch: pairs = [(outs, ins), ...] with outs[s] / ins[r] as in
+        _all_to_all_chunks. The heads form moves q, k and v^T of a head group this way -- one batch of point-to-point sends / receives
+        inside a single ncclGroupStart / End (torch.distributed.batch_isend_irecv) instead of three grouped launches per group and layer
+        (round-4 review: 96-192 exchange launches per forward). The chunk a rank keeps for itself is a device copy on the compute stream.
+        Host backends run the pairs one after another through _all_to_all_chunks."""
+        if self.skip_comm:
+            return self._Done()
+        if not self._nccl() and any(t.is_cuda for outs, ins in pairs for t in ins):   # host backend + device tensors: staged through the host
+            for outs, ins in pairs:
+                self._all_to_all_chunks(outs, ins)
+            return self._Done()
+        p2p = []                                         # RCCL, or a host backend on host tensors (the gloo tests run this very code)
+        for outs, ins in pairs:
+            for r in range(self.world):
+                if r == self.rank:
+                    outs[r].copy_(ins[r])
+                    continue
+                peer = dist.get_global_rank(self.group, r) if self.group is not None else r
+                p2p.append(dist.P2POp(dist.isend, ins[r], peer, self.group))
+                p2p.append(dist.P2POp(dist.irecv, outs[r], peer, self.group))
+        works = dist.batch_isend_irecv(p2p) if p2p else []
+
+        class _Many:
+            def wait(self_inner):
+                for w in works:
+                    w.wait()
+        done = _Many()
+        if not async_op:
+            done.wait()
+            return self._Done()
+        return done
 
     def _all_reduce_max(self, t):
         if not self._nccl() and t.is_cuda:
@@ -424,9 +497,8 @@ class ViewSharding:
             inbound = []
             for g in groups:                                          # all inbound exchanges queue up on RCCL's stream
                 sl = [slice(r * hpr + g["h0"], r * hpr + g["h0"] + g["gs"]) for r in range(W)]
-                inbound.append([self._all_to_all_chunks(list(g["q"].unbind(0)), [q[s] for s in sl], async_op=True),
-                                self._all_to_all_chunks(list(g["k"].unbind(0)), [k[s] for s in sl], async_op=True),
-                                self._all_to_all_chunks(list(g["vt"].unbind(0)), [vt[s] for s in sl], async_op=True)])
+                inbound.append([self._exchange_many([(list(g["q"].unbind(0)), [q[s] for s in sl]), (list(g["k"].unbind(0)), [k[s] for s in sl]),
+                                                     (list(g["vt"].unbind(0)), [vt[s] for s in sl])], async_op=True)])   # q | k | v^T: one grouped launch
             returns = []
             for g, works in zip(groups, inbound):
                 for w in works:
@@ -455,9 +527,8 @@ class ViewSharding:
                 works = []
                 for g in xb["groups"]:
                     sl = [slice(r * hpr + g["h0"], r * hpr + g["h0"] + g["gs"]) for r in range(W)]
-                    works += [self._all_to_all_chunks(list(g["q"].unbind(0)), [ws_g.q[s] for s in sl], async_op=True),
-                              self._all_to_all_chunks(list(g["k"].unbind(0)), [ws_g.k[s] for s in sl], async_op=True),
-                              self._all_to_all_chunks(list(g["vt"].unbind(0)), [ws_g.vt[s] for s in sl], async_op=True)]
+                    works.append(self._exchange_many([(list(g["q"].unbind(0)), [ws_g.q[s] for s in sl]), (list(g["k"].unbind(0)), [ws_g.k[s] for s in sl]),
+                                                      (list(g["vt"].unbind(0)), [ws_g.vt[s] for s in sl])], async_op=True))
                 for g in xb["groups"]:
                     back = [xb["o_back"][r * hpr + g["h0"]: r * hpr + g["h0"] + g["gs"]] for r in range(W)]
                     works.append(self._all_to_all_chunks(back, list(g["o"].unbind(0)), async_op=True))

@@ -437,6 +437,28 @@ def test_traffic_json_tool_sums_the_dispatches_of_one_attention_and_stamps_the_d
     assert rec["attention_source_digest"] == bench.attention_source_digest()
 
 
+def test_cu_budget_of_the_sharded_attention_plans(monkeypatch):
+    """Round-4 review item 5(ii): the launch plans of the global attention are told how many CUs RCCL's channels leave them
+    (sharding.available_cus -> ovg_attn_params.cus) instead of quantising against all 256."""
+    from omnivggt_official_amd import ops, sharding
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
+    assert sharding.rccl_channels() == 32 and sharding.available_cus(1) == 256 and sharding.available_cus(8) == 224
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "16")
+    assert sharding.rccl_channels() == 16 and sharding.available_cus(8) == 240
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "200")                      # a mis-set environment cannot cripple the plan
+    assert sharding.available_cus(8) == 192
+    # head groups: 2 ranks x 32 views -> 2 groups at either budget; 8 ranks x 8 views -> one launch
+    assert len(sharding.head_groups(8, 2, 32 * 1374, cus=224)) == 2 and len(sharding.head_groups(2, 8, 8 * 1374, cus=224)) == 1
+    P, bf = 1374, torch.bfloat16
+    full = ops.attn_plan(16, 64 * P, [64 * P], bf)
+    part = ops.attn_plan(16, 64 * P, [64 * P], bf, cus=224)
+    assert (full["q_tile"], full["main_rows"]) == (512, 81920) and (part["q_tile"], part["main_rows"]) == (512, 86016)   # 10 rounds of 256 CUs vs 12 of 224
+    assert ops.attn_plan(16, 64 * P, [64 * P], bf, cus=999) == full      # more than the device has: the device count
+    # per-rank launch of the 8-GPU run: the split workspace follows the budget it was planned with
+    pr = ops.attn_plan(16, 8 * P, [8 * P] * 8, bf, cus=224)
+    assert pr["splits"] >= 2 and pr["part_bytes"] == pr["splits"] * 16 * ops.pad_to(8 * P, 64) * 64 * 4
+
+
 def test_checkpoint_rehearsal_key_check(tmp_path):
     """tools/validate_checkpoint.py (round-4 review item 8): the host-side half -- a synthetic checkpoint with the reference's key set is
     written and accepted; a file with a missing / renamed / reshaped tensor is reported, not loaded."""
