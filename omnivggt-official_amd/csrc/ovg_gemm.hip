@@ -1138,12 +1138,13 @@ int launch_linear256p(const ovg_linear_params& p, hipStream_t st) {
 int choose_256(int tile_arg, bool sixteen_bit, int64_t M, int64_t N, int64_t K, bool light_epilogue_or_long_k) {
   const int tile = tile_arg & ~(OVG_TILE_R02_EPILOGUE | OVG_TILE_DMA_M);      // the A/B flags do not take part in the tile choice
   const bool legal = sixteen_bit && N % g256::BN2 == 0 && K % 32 == 0;
+#ifndef OVG_LAB_GEMM
+  if (tile == OVG_TILE_256P || (tile_arg & OVG_TILE_DMA_M)) return -2;          // lab forms: not in this build
+#endif
   if (tile == OVG_TILE_128) return 0;
   if (tile == OVG_TILE_256) return legal ? 1 : -1;
 #ifdef OVG_LAB_GEMM
   if (tile == OVG_TILE_256P) return persistent_legal(sixteen_bit, N, K) ? 2 : -1;
-#else
-  if (tile == OVG_TILE_256P || (tile_arg & OVG_TILE_DMA_M)) return -2;          // lab forms: not in this build
 #endif
   if (tile != OVG_TILE_AUTO) return -1;
   if (!legal || !light_epilogue_or_long_k || M < 20000) return 0;

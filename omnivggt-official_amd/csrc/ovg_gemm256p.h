@@ -97,25 +97,7 @@ OVG_DEV P reload_params() {
   return out;
 }
 
-// Raw buffer descriptor (4 SGPRs): base, stride 0, num_records = bytes, untyped dword format. Lanes whose offset (VGPR offset + immediate;
-// the SGPR offset is NOT range-checked) reaches num_records read as zero and fetch nothing.
-typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
-OVG_DEV i32x4 make_srd(const void* base, uint32_t bytes) {
-  const uint64_t a = reinterpret_cast<uint64_t>(base);
-  i32x4 r;
-  r[0] = __builtin_amdgcn_readfirstlane((int32_t)(uint32_t)a);
-  r[1] = __builtin_amdgcn_readfirstlane((int32_t)((uint32_t)(a >> 32) & 0xffffu));
-  r[2] = __builtin_amdgcn_readfirstlane((int32_t)bytes);
-  r[3] = 0x00020000;
-  return r;
-}
-// LDS-DMA of one 16-byte granule per lane through a buffer descriptor: lane l lands at lds_dst + 16 l (lds_dst wave-uniform, in M0), its
-// source is srd.base + voff + soff. Inline asm for the reason given at lds_dma16 (ovg_common.h) -- measured on this kernel: with the builtin
-// form (__builtin_amdgcn_raw_ptr_buffer_load_lds) hipcc put s_waitcnt vmcnt(0) in front of the fragment reads of EVERY k-stage, draining the
-// ring it cannot tell apart from the slot being read. The transfers are covered by the explicit counted waits of run_piece.
-OVG_DEV void buffer_dma16(uint32_t lds_dst, uint32_t voff, const i32x4 srd, uint32_t soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_dst), "v"(voff), "s"(srd), "s"(soff) : "memory");
-}
+// (make_srd / buffer_dma16: ovg_common.h)
 
 // Everything a workgroup keeps across its pieces: scalars only. The per-lane constants (DMA offsets, fragment offset) are recomputed at the
 // start of every piece from an opaque copy of the thread id, so that they do not occupy VGPRs across the epilogues.

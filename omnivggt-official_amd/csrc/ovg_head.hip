@@ -145,6 +145,57 @@ template <typename T> OVG_DEV f32x4 load4(const T* src) {
   return f32x4{static_cast<float>(v[0]), static_cast<float>(v[1]), static_cast<float>(v[2]), static_cast<float>(v[3])};
 }
 
+// Epilogue of both conv kernels on a wave's 64 (n) x 16 MT (m) accumulator block: bias, UV position embedding, residual / skip sums, ReLU,
+// ConvTranspose pixel scatter. Everything that depends on the column only (output channel, pixel-shuffle offset, bias) is resolved once per
+// 16-column block, outside the row loop.
+template <typename T, bool OUT_F32, int MT>
+OVG_DEV void conv_epilogue(const ovg_conv_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int n_w0, const int OH, const int OW, const int M) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
+  const int s = p.upshuffle > 1 ? p.upshuffle : 1;
+  const int half = p.Cout >> 1;
+  int co[4], dy[4], dx[4];
+  bool live[4];
+  f32x4 bias[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int n = n_w0 + nt * 16 + 4 * g;
+    co[nt] = n; dy[nt] = 0; dx[nt] = 0;
+    live[nt] = true;
+    if (s > 1) {
+      const int q = n / p.Cout;
+      co[nt] = n - q * p.Cout;
+      dy[nt] = q / s; dx[nt] = q - dy[nt] * s;
+    } else if (n >= p.Cout) {
+      live[nt] = false;                                 // zero-padded weight rows (Cout < the tile's columns)
+      co[nt] = 0;
+    }
+    bias[nt] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + co[nt]) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m_w0 + mt * 16 + lr;
+    if (m >= M) continue;
+    const int img = m / (OH * OW), rem2 = m - img * (OH * OW);
+    const int oy = rem2 / OW, ox = rem2 - oy * OW;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      if (!live[nt]) continue;
+      const int c = co[nt];
+      const int64_t opix = s > 1 ? ((int64_t)img * OH * s + (oy * s + dy[nt])) * ((int64_t)OW * s) + (ox * s + dx[nt]) : (int64_t)m;
+      f32x4 v = acc[nt][mt] + bias[nt];
+      if (p.pos_x) {
+        if (c < half) v += *reinterpret_cast<const f32x4*>(p.pos_x + (int64_t)ox * half + c);
+        else v += *reinterpret_cast<const f32x4*>(p.pos_y + (int64_t)oy * half + (c - half));
+      }
+      if (p.add1) v += load4<T>(static_cast<const T*>(p.add1) + opix * p.ld1 + c);
+      if (p.add2) v += load4<T>(static_cast<const T*>(p.add2) + opix * p.ld2 + c);
+      if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      if constexpr (OUT_F32) *reinterpret_cast<f32x4*>(static_cast<float*>(p.y) + opix * p.ldy + c) = v;
+      else store4<T>(static_cast<T*>(p.y) + opix * p.ldy + c, v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
 template <typename T, bool OUT_F32>
 __global__ __launch_bounds__(256, 2) void conv_kernel(ovg_conv_params p, int OH, int OW, int M, int ntiles_n) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128];
@@ -161,43 +212,28 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ovg_conv_params p, int OH,
 
   f32x4 acc[4][4];
   conv_mainloop<T>(p, M, OH, OW, m0, n0, lds, acc);
+  const int wave = threadIdx.x >> 6;
+  conv_epilogue<T, OUT_F32, 4>(p, acc, m0 + (wave & 1) * 64, n0 + (wave >> 1) * 64, OH, OW, M);
+}
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wn = wave >> 1, wm = wave & 1, g = lane >> 4, lr = lane & 15;
-  const int s = p.upshuffle > 1 ? p.upshuffle : 1;
-  const int half = p.Cout >> 1;
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = m0 + wm * 64 + mt * 16 + lr;
-    if (m >= M) continue;
-    const int img = m / (OH * OW), rem2 = m - img * (OH * OW);
-    const int oy = rem2 / OW, ox = rem2 - oy * OW;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int n = n0 + wn * 64 + nt * 16 + 4 * g;
-      int co = n;
-      int64_t opix = m;
-      if (s > 1) {
-        const int q = n / p.Cout;
-        co = n - q * p.Cout;
-        const int dy = q / s, dx = q - dy * s;
-        opix = ((int64_t)img * OH * s + (oy * s + dy)) * ((int64_t)OW * s) + (ox * s + dx);
-      } else if (n >= p.Cout) {
-        continue;                                   // zero-padded weight rows (Cout < 128)
-      }
-      f32x4 v = acc[nt][mt];
-      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
-      if (p.pos_x) {
-        if (co < half) v += *reinterpret_cast<const f32x4*>(p.pos_x + (int64_t)ox * half + co);
-        else v += *reinterpret_cast<const f32x4*>(p.pos_y + (int64_t)oy * half + (co - half));
-      }
-      if (p.add1) v += load4<T>(static_cast<const T*>(p.add1) + opix * p.ld1 + co);
-      if (p.add2) v += load4<T>(static_cast<const T*>(p.add2) + opix * p.ld2 + co);
-      if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-      if constexpr (OUT_F32) *reinterpret_cast<f32x4*>(static_cast<float*>(p.y) + opix * p.ldy + co) = v;
-      else store4<T>(static_cast<T*>(p.y) + opix * p.ldy + co, v[0], v[1], v[2], v[3]);
-    }
-  }
+#include "ovg_conv256.h"
+
+// 256 x 256 form (16-bit modes, GEMM columns a multiple of 256, two images within 32-bit byte offsets): ovg_conv256.h
+template <typename T>
+__global__ __launch_bounds__(512) void conv256_kernel(ovg_conv_params p, int OH, int OW, int M, int ntiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_c256[];
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mtiles = (M + 255) / 256;
+  const int per_group = 4 * ntiles_n;                   // m-fastest inside groups of 4 m-tiles x all n-tiles (ovg_gemm.hip TILE_GROUP256)
+  const int grp = lid / per_group, rem = lid - grp * per_group;
+  const int m_first = grp * 4;
+  const int gsz = (mtiles - m_first) < 4 ? (mtiles - m_first) : 4;
+  const int tm = m_first + rem % gsz, tn = rem / gsz;
+  const int m0 = tm * 256, n0 = tn * 256;
+  f32x4 acc[4][8];
+  c256::mainloop<T>(p, M, OH, OW, m0, n0, lds_c256, acc);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  conv_epilogue<T, false, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, OH, OW, M);
 }
 
 // ---------------------------------------------------------------------------
@@ -337,6 +373,30 @@ extern "C" int ovg_conv(const ovg_conv_params* p, void* stream) {
   const int M = (int)M64, nt = p->w_rows / 128;
   const dim3 grid((unsigned)(((M + 127) / 128) * nt)), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // 256 x 256 LDS-DMA form (ovg_conv256.h): 16-bit, 16-bit output, every GEMM column real (w_rows == the GEMM's columns, a multiple of 256),
+  // 32-channel k-stages, enough pixels for at least one round of the chip, and two images within the 32-bit byte offsets of its descriptor
+  const int64_t two_images = 2 * (int64_t)p->H * p->W * p->ldx * 2;
+  const int gemm_cols = s * s * p->Cout;
+  if (p->dtype != OVG_F32 && !p->out_f32 && p->w_rows == gemm_cols && gemm_cols % 256 == 0 && p->Cin % 32 == 0 && M >= 16384 &&
+      two_images < ((int64_t)1 << 32) - 65536 && (int64_t)p->w_rows * p->ksize * p->ksize * p->Cin * 2 < ((int64_t)1 << 32)) {
+    const int nt2 = p->w_rows / 256;
+    const dim3 grid2((unsigned)(((M + 255) / 256) * nt2));
+    // > 64 KB of dynamic LDS is a per-device opt-in of the kernel: done once per (kernel, device), remembered in a bit mask (idempotent; a
+    // race between two threads sets it twice)
+    static unsigned opted[2] = {0u, 0u};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return OVG_E_LAUNCH;
+    const int which = p->dtype == OVG_BF16 ? 0 : 1;
+    if (dev >= 32 || !((opted[which] >> dev) & 1u)) {
+      const void* fn = which == 0 ? reinterpret_cast<const void*>(conv256_kernel<bf16_t>) : reinterpret_cast<const void*>(conv256_kernel<f16_t>);
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, c256::LDS_BYTES) != hipSuccess) return OVG_E_LAUNCH;
+      if (dev < 32) opted[which] |= 1u << dev;
+    }
+    if (which == 0) OVG_LAUNCH((conv256_kernel<bf16_t>), grid2, dim3(512), c256::LDS_BYTES, st, *p, OH, OW, M, nt2);
+    else OVG_LAUNCH((conv256_kernel<f16_t>), grid2, dim3(512), c256::LDS_BYTES, st, *p, OH, OW, M, nt2);
+    OVG_CHECK_LAUNCH();
+    return OVG_OK;
+  }
   if (p->dtype == OVG_BF16) {
     if (p->out_f32) OVG_LAUNCH((conv_kernel<bf16_t, true>), grid, block, 0, st, *p, OH, OW, M, nt);
     else OVG_LAUNCH((conv_kernel<bf16_t, false>), grid, block, 0, st, *p, OH, OW, M, nt);

@@ -520,6 +520,13 @@ def test_heads(quick):
         conv_case("3x3_128to32_f32out", 1, 70, 66, 128, 32, k=3, relu=True, out_f32=True, pad_rows=True)
         if not quick:
             conv_case("1x1_256", 1, 148, 148, 256, 256)
+        # the 256 x 256 LDS-DMA conv kernel (ovg_conv256.h; 16-bit modes, GEMM columns % 256 == 0, >= 16384 output pixels): every tap / border /
+        # epilogue form it serves, tiles that straddle two images (ragged widths), stride 2, the ConvTranspose scatter and the UV tables
+        conv_case("c256_3x3_add2_relu_256_two_images", 3, 77, 75, 256, 256, k=3, relu=True, adds=2)
+        conv_case("c256_3x3_nobias_relu_512to256", 1, 148, 148, 512, 256, k=3, relu=True, bias=False)
+        conv_case("c256_1x1_pos_2048to512", 12, 37, 37, 2048, 512, pos=True)
+        conv_case("c256_convT2_512", 12, 37, 37, 512, 512, up=2)
+        conv_case("c256_3x3s2_1024", 14, 74, 74, 1024, 1024, k=3, stride=2)
         # bilinear align_corners resize (+ UV tables)
         for tag, n, H, W, OH, OW, c, pos in (("19to37", 2, 19, 19, 37, 37, 256, False), ("37to74", 1, 37, 37, 74, 74, 256, False),
                                              ("148to296", 1, 148, 148, 296, 296, 256, False), ("296to518_pos", 1, 296, 296, 518, 518, 128, True)):
