@@ -176,7 +176,7 @@ def test_two_even_shards_head_parallel_emulated_match_monolithic():
     assert sharding.head_groups(hpr) == [(0, 4), (4, 4)]
     # force the two-group pipeline for this small case (head_groups() itself would keep one launch at 2 x 1374 tokens)
     orig_groups = sharding.head_groups
-    sharding.head_groups = lambda h, world=1, n_tokens=None: orig_groups(h)
+    sharding.head_groups = lambda h, world=1, n_tokens=None, cus=256: orig_groups(h)
     try:
         ranks = _emulate_heads(agg, inputs, world, parts, P)
     finally:
