@@ -96,6 +96,24 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     print("%-62s grid %-9s calls %3d  avg %9.1f us  total %9.1f us  %5.1f %%" % (k[0], k[1], len(v), sum(v) / len(v), sum(v), 100 * sum(v) / tot))
 PY
       find "$O/prof_e2e_S8" -name "*.csv" -size +1M -delete ;;
+    pmc_lite)   # SQ / GRBM counter passes on the shipped bf16 attention and GEMM launches (own runs, only --kernel-trace next to --pmc)
+      P=$O/prof_pmc; mkdir -p "$P"
+      (cd /tmp && export TMPDIR=/tmp
+       run() { "$@" > "$P/last.log" 2>&1 || { echo "   FAILED: $*"; tail -4 "$P/last.log"; }; }
+       i=0
+       for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+                  "SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE"; do
+         i=$((i + 1))
+         for v in 8 64; do
+           run rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$P/attn_S${v}_pmc$i" -- python "$R/tests/bench_kernels.py" attn --modes global --views $v --variants 0 --rounds 1 --target-ms 60
+           run rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$P/gemm_S${v}_pmc$i" -- python "$R/tests/bench_kernels.py" gemm --views $v --tiles 0 --rounds 1 --target-ms 5
+         done
+       done)
+      python tools/pmc_summary.py "$P"/attn_S* > "$O/pmc_attention.txt" 2>&1
+      python tools/pmc_summary.py "$P"/gemm_S64_* > "$O/pmc_gemm.txt" 2>&1
+      python tools/pmc_summary.py "$P"/gemm_S8_* > "$O/pmc_gemm_S8.txt" 2>&1
+      grep -h "grid=\|matrix pipe\|effective clock" "$O/pmc_attention.txt" "$O/pmc_gemm_S8.txt" | cut -c1-170 | head -40
+      find "$P" -name "*.csv" -size +1M -delete ;;
     gemm_m)     (timeout 400 python tests/gpu_selftest.py --only gemm256m ${OVG_SELFTEST_ARGS:---quick} 2>&1 | grep -v amdgpu.ids | grep -E "FAIL|SELFTEST|Error|error|Traceback|raise|fault|core|gemm256m:" | head -60) | tee "$O/gemm256m_selftest.txt" ;;
     gemm_p)     (timeout 400 python tests/gpu_selftest.py --only gemm256p ${OVG_SELFTEST_ARGS:---quick} 2>&1 | grep -v amdgpu.ids | grep -E "FAIL|SELFTEST|Error|error|Traceback|raise|fault|core|gemm256p:" | head -60) | tee "$O/gemm256p_selftest.txt" ;;
     gemm_tl)    (timeout 900 python tools/probes/gemm_timeline.py ${OVG_TL_ARGS:-} 2>&1 | grep -v amdgpu.ids | tail -80) | tee "$O/gemm_timeline.txt" ;;
