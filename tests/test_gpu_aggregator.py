@@ -515,40 +515,6 @@ def test_batch_of_two_scenes_full_depth_model_forward():
         torch.cuda.empty_cache()
 
 
-def test_full_depth_16_views_full_aux_vs_oracle_model_forward():
-    """Second full-depth BASELINE case (round-4 review item 6): configs[2] -- 16 views 518^2 with depth AND camera on every view --
-    through the full model against oracle.model_forward (omnivggt_aggregator.py:130-256; ~4-5 min on the host cores). f32 and
-    split-f16 <= 1e-4 on the tokens of layers 0 / 4 / 11 / 17 / 23 and on pose / depth / points; bf16 tokens <= 3e-2."""
-    S, dgi, cgi = 16, list(range(16)), list(range(16))
-    sd = common.full_state_dict()
-    inp = orc.synthetic_inputs(S)
-    threads = torch.get_num_threads()
-    torch.set_num_threads(min(64, os.cpu_count()))
-    try:
-        with torch.no_grad():
-            ref = orc.model_forward(sd, inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
-    finally:
-        torch.set_num_threads(threads)
-    rtok = [ref["_tokens"][l][0, :, ::7, ::8] for l in common.TOK_LAYERS]
-    keys = ("pose_enc", "depth", "depth_conf", "world_points", "world_points_conf")
-    rpred = {k: ref[k] for k in keys}
-    del ref
-    m = build(sd, 24, 24, torch.float32)
-    for dtype, tol in ((torch.float32, F32_TOL), (L.F32X, F32_TOL), (torch.bfloat16, 3e-2)):
-        m.set_compute_dtype(dtype)
-        out = run_full(m, S, dgi, cgi)
-        toks, _ = run_agg(m, S, dgi, cgi)
-        errs = {"tok_L%d" % l: common.max_rel(toks[l][0, :, ::7, ::8].cpu(), r) for l, r in zip(common.TOK_LAYERS, rtok)}
-        for k in keys:
-            assert torch.isfinite(out[k]).all(), (dtype, k)
-            errs[k] = common.max_rel(out[k].float().cpu(), rpred[k])
-        print("16 views full aux, full depth, %s vs oracle.model_forward: %s" % (repr(dtype).replace("torch.", ""), ", ".join("%s %.2e" % kv for kv in errs.items())))
-        gate = errs if dtype is not torch.bfloat16 else {k: v for k, v in errs.items() if k.startswith("tok_")}
-        assert max(gate.values()) <= tol, (dtype, errs)
-        del out, toks
-        torch.cuda.empty_cache()
-
-
 def test_duplicate_camera_indices_follow_the_reference(reduced):
     """the reference tolerates a view listed twice in camera_gt_index (index_select + index assignment,
     omnivggt_aggregator.py:158-178): the duplicate counts twice in the mean camera distance of normalize_extrinsics (:85-105) and the

@@ -114,6 +114,7 @@ PY
       python tools/pmc_summary.py "$P"/gemm_S8_* > "$O/pmc_gemm_S8.txt" 2>&1
       grep -h "grid=\|matrix pipe\|effective clock" "$O/pmc_attention.txt" "$O/pmc_gemm_S8.txt" | cut -c1-170 | head -40
       find "$P" -name "*.csv" -size +1M -delete ;;
+    slow)       (OVG_RUN_SLOW=1 timeout 2400 python -m pytest tests -m gpu_slow -q -s 2>&1 | grep -E "vs oracle|passed|failed|Error" | cut -c1-400) | tee "$O/gpu_slow_tests.txt" ;;
     gemm_m)     (timeout 400 python tests/gpu_selftest.py --only gemm256m ${OVG_SELFTEST_ARGS:---quick} 2>&1 | grep -v amdgpu.ids | grep -E "FAIL|SELFTEST|Error|error|Traceback|raise|fault|core|gemm256m:" | head -60) | tee "$O/gemm256m_selftest.txt" ;;
     gemm_p)     (timeout 400 python tests/gpu_selftest.py --only gemm256p ${OVG_SELFTEST_ARGS:---quick} 2>&1 | grep -v amdgpu.ids | grep -E "FAIL|SELFTEST|Error|error|Traceback|raise|fault|core|gemm256p:" | head -60) | tee "$O/gemm256p_selftest.txt" ;;
     gemm_tl)    (timeout 900 python tools/probes/gemm_timeline.py ${OVG_TL_ARGS:-} 2>&1 | grep -v amdgpu.ids | tail -80) | tee "$O/gemm_timeline.txt" ;;
