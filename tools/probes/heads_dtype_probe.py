@@ -11,7 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))  # tests/common.py (the goldens checker) imports the oracle; this probe is a test-side measurement, not product
 import common  # noqa: E402
 from omnivggt_official_amd.model import OmniVGGT  # noqa: E402
 

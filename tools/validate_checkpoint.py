@@ -25,7 +25,6 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
 def manifest():
@@ -64,7 +63,7 @@ def rel(a, b):
 
 
 def validate(path, views, aux, depth, device="cuda"):
-    import aggregator_oracle as orc
+    import bench  # synthetic_inputs: the SURVEY 8d inputs, generated without the oracle (nothing under oracle/ is used outside tests)
     from omnivggt_official_amd import lib as L
     from omnivggt_official_amd.model import OmniVGGT
     L.require_gpu()
@@ -76,7 +75,7 @@ def validate(path, views, aux, depth, device="cuda"):
     modes = [("f32", torch.float32), ("f32x", L.F32X), ("bf16", torch.bfloat16), ("f16", torch.float16)]
     keys = ("pose_enc", "depth", "depth_conf", "world_points", "world_points_conf")
     for S in views:
-        inp = {k: v.to(device) for k, v in orc.synthetic_inputs(S).items()}
+        inp = bench.synthetic_inputs(S, device, aux=True)
         dgi = list(range(0, S, 2)) if aux else []
         cgi = list(range(S)) if aux else []
         ref_tok, ref_pred, rows = None, None, {}
