@@ -506,11 +506,14 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
 
 // split-f16 mode (OVG_F16X2): one launch of 256-row tiles -- 8 waves x 2 q blocks, lazy-rescale softmax, a 3-slot LDS-DMA ring of
 // [K hi | V^T hi | K lo | V^T lo] tiles (96 KB, one workgroup per CU), three f16 MFMAs per product
+#ifndef OVG_ATTN_X3_RING
+#define OVG_ATTN_X3_RING 3
+#endif
 int dispatch_x3(const ovg_attn_params& p, hipStream_t st) {
   Plan16 pl{};
   pl.variant = 90; pl.bq = 256; pl.splits = 1; pl.total_tiles = total_key_tiles(p); pl.per_split = pl.total_tiles;
   pl.main_rows = p.nq; pl.tail_bq = 0; pl.tail_splits = 0;
-  return launch_attn16<f16_t, 2, 8, 1, 2, true, 3, true>(p, pl, st);
+  return launch_attn16<f16_t, 2, 8, 1, 2, true, OVG_ATTN_X3_RING, true>(p, pl, st);
 }
 
 }  // namespace

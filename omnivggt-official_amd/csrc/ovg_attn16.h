@@ -99,8 +99,25 @@ OVG_DEV u32x4 pack2(const f32x4 a, const f32x4 b) {
   return r;
 }
 
-// P tile -> (hi, lo) f16 fragments of the split-f16 mode: hi = f16(p), lo = f16(p - hi); p <= 2^8 (lazy rescale), no saturation needed
+// P tile -> (hi, lo) f16 fragments of the split-f16 mode: hi = f16(p), lo = f16(p - hi); p <= 2^8 (lazy rescale), no saturation needed.
+// OVG_ATTN_X3_SPLIT 1 (r05): 3 VALU per value pair instead of ~11 -- v_cvt_pk_f16_f32 for the hi pair, then v_fma_mixlo/mixhi_f16
+// compute f16(p * 1.0 - f32(hi half)) straight from the packed hi register (the f32 difference is exact, so the bits equal form 0's).
+#ifndef OVG_ATTN_X3_SPLIT
+#define OVG_ATTN_X3_SPLIT 1
+#endif
 OVG_DEV void pack2_hilo(const f32x4 a, const f32x4 b, u32x4& hi, u32x4& lo) {
+#if OVG_ATTN_X3_SPLIT
+  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h[i]) : "v"(v[2 * i]), "v"(v[2 * i + 1]));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l[i]) : "v"(v[2 * i]), "v"(h[i]));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l[i]) : "v"(v[2 * i + 1]), "v"(h[i]));
+  }
+  hi = u32x4{h[0], h[1], h[2], h[3]};
+  lo = u32x4{l[0], l[1], l[2], l[3]};
+#else
   f16_t h[8], l[8];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -109,6 +126,27 @@ OVG_DEV void pack2_hilo(const f32x4 a, const f32x4 b, u32x4& hi, u32x4& lo) {
   }
   __builtin_memcpy(&hi, h, 16);
   __builtin_memcpy(&lo, l, 16);
+#endif
+}
+
+// lacc += sa + sb on the packed-f32 adder (r05, OVG_ATTN_X3_PKSUM 1): 4 v_pk_add_f32 per 8 values instead of 8 v_add_f32; the four registers
+// of lacc are lane-partial sums that are reduced once behind the loop, so only the ORDER of the f32 additions differs from form 0
+#ifndef OVG_ATTN_X3_PKSUM
+#define OVG_ATTN_X3_PKSUM 1
+#endif
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+OVG_DEV void rowsum_acc(f32x4& lacc, const f32x4 sa, const f32x4 sb) {
+#if OVG_ATTN_X3_PKSUM
+  f32x2_t l0 = {lacc[0], lacc[1]}, l1 = {lacc[2], lacc[3]};
+  const f32x2_t a0 = {sa[0], sa[1]}, a1 = {sa[2], sa[3]}, b0 = {sb[0], sb[1]}, b1 = {sb[2], sb[3]};
+  asm("v_pk_add_f32 %0, %0, %1" : "+v"(l0) : "v"(a0));
+  asm("v_pk_add_f32 %0, %0, %1" : "+v"(l1) : "v"(a1));
+  asm("v_pk_add_f32 %0, %0, %1" : "+v"(l0) : "v"(b0));
+  asm("v_pk_add_f32 %0, %0, %1" : "+v"(l1) : "v"(b1));
+  lacc = f32x4{l0[0], l0[1], l1[0], l1[1]};
+#else
+  lacc += sa + sb;
+#endif
 }
 
 // One pass over all key tiles of all segments for the wave's QB x 16 query rows; leaves the un-normalised
@@ -119,6 +157,11 @@ OVG_DEV void pack2_hilo(const f32x4 a, const f32x4 b, u32x4& hi, u32x4& lo) {
 // [K hi | V^T hi | K lo | V^T lo] -- and both contractions run three MFMAs per product into the same f32 accumulator, small terms first:
 //   S = K_lo Q_hi + K_hi Q_lo + K_hi Q_hi,   O += V_lo P_hi + V_hi P_lo + V_hi P_hi,   P = (hi, lo) split of exp2(S - m) in registers;
 // the row sums are exact f32 sums of P on the VALU (the matrix pipe is the bound here: 104 MFMAs against ~100 VALU per tile at QB = 2).
+// r05 (profiles/r05_attention_x3_ab.txt): the (hi, lo) split through v_cvt_pk_f16_f32 + v_fma_mixlo/mixhi_f16 and packed-f32 row sums cut the
+// VALU work of a tile from ~190 to ~140 instructions for +1.9 ... 2.1 %; a 5-slot ring with a barrier every 2 tiles (all 160 KB of LDS) measured
+// -0.6 ... -1.2 %, and a loop that issues QK^T of tile j + 1 inside the exp / split block of tile j (4-slot ring, 191 VGPRs, no spill,
+// MFMA / VALU interleaved by hipcc as intended) -2.2 ... -2.6 % -- the kernel issues 1400 TFLOP/s of f16 MFMAs, the same rate as the bf16
+// kernel with its row-sum MFMAs: neither VALU issue nor phase alignment of the two waves of a SIMD is what holds it there (section 5.1).
 template <typename T, int QB, int WAVES, int SM, bool VSUM = false, int DMA = 0, bool X3 = false>   // VSUM: row sums on the VALU (experiment, variant 31) instead of the ones-MFMA; DMA: 0 = register staging, R = 2 B + 1 (3, 5, 7, 9): K / V^T tiles by LDS-DMA into a ring of R slots, B + 1 tiles ahead, one workgroup barrier every B tiles
 OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int bh, const int q0, const int t_begin, const int total_tiles,
                        f32x4 (&o)[QB][4], f32x4 (&lacc)[QB], f32x4 (&negm)[QB]) {   // key tiles [t_begin, t_begin + total_tiles) of the flattened segment list
@@ -333,7 +376,7 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
         pack2_hilo(sa[qb], sb[qb], ph[qb], pl[qb]);
-        lacc[qb] += sa[qb] + sb[qb];                  // exact f32 row sums, lane-partial, reduced once after the loop
+        rowsum_acc(lacc[qb], sa[qb], sb[qb]);         // exact f32 row sums, lane-partial, reduced once after the loop
       }
       const int voff = ((4 * u + g) ^ sx) << 4;
 #pragma unroll

@@ -1080,8 +1080,18 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--bench", action="store_true")
     ap.add_argument("--only", default="")
+    ap.add_argument("--alt-lib", default="", help="name of an alternate build under tools/probes/_build/ (build_alt.py) to run the checks on instead of the product library")
     args = ap.parse_args()
     L.require_gpu()
+    if args.alt_lib:
+        import ctypes
+        alt = ctypes.CDLL(os.path.join(ROOT, "tools", "probes", "_build", args.alt_lib, "libomnivggt_hip.so"))
+        for name, (res, a) in L.SYMBOLS.items():
+            f = getattr(alt, name)
+            f.restype, f.argtypes = res, a
+        L.load()
+        L._lib = alt
+        print("checks run on the alternate build", args.alt_lib, flush=True)
     print(L.load().ovg_build_info().decode(), torch.cuda.get_device_name(0), flush=True)
     tests = {"probe": test_probe, "layernorm": test_layernorm, "linear": lambda: test_linear(args.quick), "qkv": lambda: test_qkv(args.quick),
              "attn": lambda: test_attn(args.quick), "embed": test_embed, "block": lambda: test_block(args.quick),
