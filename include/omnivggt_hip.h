@@ -49,8 +49,9 @@ extern "C" {
  *    ovg_attn_params.fallback_count / ovg_block_params.attn_fallback_count (telemetry of the speculative bf16 softmax)
  * 9: split-KV partials are f32 (ovg_attn_plan_out.part_bytes doubles) and a launch may split only the rows beyond its last full round
  *    along the keys (key-split tail, reported through main_rows / tail_q_tile); OVG_TILE_256P / OVG_TILE_DMA_M name the round-5 lab GEMM
- *    forms (OVG_E_UNSUPPORTED unless the library was built with -DOVG_LAB_GEMM) */
-#define OVG_ABI_VERSION 9
+ *    forms (OVG_E_UNSUPPORTED unless the library was built with -DOVG_LAB_GEMM)
+ * 10: ovg_dpt_tail -- the output stage of the DPT head (upsample + position embedding + conv3x3 + ReLU + conv1x1 + activation) as one launch */
+#define OVG_ABI_VERSION 10
 
 enum { OVG_BF16 = 0, OVG_F16 = 1, OVG_F32 = 2,
        /* split-f16 ("f32x", the <= 1e-4 mode with throughput): a value x is stored as hi = f16(x) (saturated at +-65504) in the tensor the
@@ -460,6 +461,24 @@ typedef struct {
   int64_t npix; int out_dim; int activation;
 } ovg_dpt_out_params;
 int ovg_dpt_out(const ovg_dpt_out_params*, void* stream);
+
+/* The whole output stage of the DPT head in one launch (ABI 10; 16-bit dtypes): what ovg_upsample (with the UV position tables) ->
+ * ovg_conv (k = 3, Cin = 128, Cout = 32, relu, out_f32) -> ovg_dpt_out compute, without the upsampled map (n x OH x OW x 128) or the 32-channel
+ * map ever reaching HBM (dpt_head.py:242-258, head_act.py:61-125):
+ *   x [n, H, W, 128] dtype (pixel stride ldx elements)  --bilinear, align_corners-->  [n, OH, OW, 128] (+ pos_x [OW, 64] / pos_y [OH, 64] f32,
+ *   both or neither), rounded to dtype as ovg_upsample does;  w1 [>= 32 rows, 9 * 128] dtype taps-major (row stride ldw1 elements: the
+ *   zero-padded matrix ovg_conv takes is fine), b1 f32 [32] or NULL;  w2 f32 [out_dim, 32], b2 f32 [out_dim];
+ *   val f32 [n, OH, OW, out_dim - 1], conf f32 [n, OH, OW]; activation as ovg_dpt_out_params.
+ * Any other channel count / dtype is OVG_E_UNSUPPORTED (callers run the three-launch form). */
+typedef struct {
+  const void* x; int64_t ldx;
+  const float* pos_x; const float* pos_y;
+  const void* w1; int64_t ldw1; const float* b1;
+  const float* w2; const float* b2;
+  float* val; float* conf;
+  int64_t n_img; int H; int W; int OH; int OW; int C; int out_dim; int activation; int dtype;
+} ovg_dpt_tail_params;
+int ovg_dpt_tail(const ovg_dpt_tail_params*, void* stream);
 
 /* ------------------------------------------------------------------ *
  * Post-processing on the device: depth maps -> world-frame point maps,

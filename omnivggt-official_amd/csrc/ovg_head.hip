@@ -307,6 +307,8 @@ __global__ __launch_bounds__(256) void dpt_out_kernel(ovg_dpt_out_params p) {
   }
 }
 
+#include "ovg_dpt_tail.h"
+
 // ---------------------------------------------------------------------------
 // depth -> world points (utils/geometry.py:151-266); HBM bound: 4 B read + 12 B written per pixel
 // ---------------------------------------------------------------------------
@@ -433,6 +435,37 @@ extern "C" int ovg_dpt_out(const ovg_dpt_out_params* p, void* stream) {
   if (!p || !p->h || !p->w2 || !p->b2 || !p->val || !p->conf || p->npix <= 0) return OVG_E_ARG;
   if (p->out_dim < 2 || p->out_dim > 4 || (p->activation != 0 && p->activation != 1) || !al16(p->h)) return OVG_E_ARG;
   OVG_LAUNCH(dpt_out_kernel, dim3(grid_1d(p->npix, 256, 1 << 20)), dim3(256), 0, static_cast<hipStream_t>(stream), *p);
+  OVG_CHECK_LAUNCH();
+  return OVG_OK;
+}
+
+extern "C" int ovg_dpt_tail(const ovg_dpt_tail_params* p, void* stream) {
+  if (!p || !p->x || !p->w1 || !p->w2 || !p->b2 || !p->val || !p->conf) return OVG_E_ARG;
+  if (p->n_img <= 0 || p->H <= 0 || p->W <= 0 || p->OH <= 1 || p->OW <= 1) return OVG_E_ARG;
+  if (p->out_dim < 2 || p->out_dim > 4 || (p->activation != 0 && p->activation != 1)) return OVG_E_ARG;
+  if ((p->pos_x == nullptr) != (p->pos_y == nullptr)) return OVG_E_ARG;
+  if (p->dtype != OVG_BF16 && p->dtype != OVG_F16) return p->dtype == OVG_F32 || p->dtype == OVG_F16X2 ? OVG_E_UNSUPPORTED : OVG_E_DTYPE;
+  if (p->C != dtail::CI) return OVG_E_UNSUPPORTED;
+  if (p->ldx < p->C || (p->ldx % 8) || p->ldw1 < 9 * p->C || (p->ldw1 % 8) || !al16(p->x) || !al16(p->w1)) return OVG_E_ARG;
+  if ((p->pos_x && (!al16(p->pos_x) || !al16(p->pos_y))) || (p->b1 && !al16(p->b1))) return OVG_E_ARG;
+  const int tiles_x = (p->OW + dtail::TW - 1) / dtail::TW, tiles_y = (p->OH + dtail::TH - 1) / dtail::TH;
+  const int64_t nt64 = p->n_img * tiles_x * tiles_y;
+  if (nt64 > (1 << 30)) return OVG_E_ARG;
+  const float sy = (float)(p->H - 1) / (float)(p->OH - 1), sx = (float)(p->W - 1) / (float)(p->OW - 1);   // as ovg_upsample
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return OVG_E_LAUNCH;
+  static unsigned opted[2] = {0u, 0u};                       // > 64 KB of dynamic LDS: per-device opt-in, once (as in ovg_conv)
+  const int which = p->dtype == OVG_BF16 ? 0 : 1;
+  if (dev >= 32 || !((opted[which] >> dev) & 1u)) {
+    const void* fn = which == 0 ? reinterpret_cast<const void*>(dtail::dpt_tail_kernel<bf16_t>) : reinterpret_cast<const void*>(dtail::dpt_tail_kernel<f16_t>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, dtail::LDS_B) != hipSuccess) return OVG_E_LAUNCH;
+    if (dev < 32) opted[which] |= 1u << dev;
+  }
+  const int ntiles = (int)nt64;
+  const dim3 grid((unsigned)(ntiles < cus ? ntiles : cus)), block(dtail::NT);   // persistent: one workgroup per CU (156 KB of LDS each)
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (which == 0) OVG_LAUNCH((dtail::dpt_tail_kernel<bf16_t>), grid, block, dtail::LDS_B, st, *p, sy, sx, tiles_x, tiles_y, ntiles);
+  else OVG_LAUNCH((dtail::dpt_tail_kernel<f16_t>), grid, block, dtail::LDS_B, st, *p, sy, sx, tiles_x, tiles_y, ntiles);
   OVG_CHECK_LAUNCH();
   return OVG_OK;
 }

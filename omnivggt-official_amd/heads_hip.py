@@ -51,6 +51,7 @@ class HipDPTHead:
         self._packed = None
         self._key = None
         self._pos = {}
+        self.fused_tail = True       # False: the three-launch output stage (ovg_upsample -> ovg_conv -> ovg_dpt_out), kept for A/B and the f32 modes
 
     # -- weights ---------------------------------------------------------------------------------
     def _pack(self, dtype, device):
@@ -155,7 +156,11 @@ class HipDPTHead:
             u = ops.conv(u, F[lvl]["out"][0], F[lvl]["out"][1], dtype, 256, ksize=1)
             y = ops.upsample(u, size[0], size[1], dtype)
         y = ops.conv(y, P["oc1"][0], P["oc1"][1], dtype, 128, ksize=3)
-        y = ops.upsample(y, ph * ps, pw * ps, dtype, pos=self._postab(128, ph * ps, pw * ps, W, H, dev))
+        pos = self._postab(128, ph * ps, pw * ps, W, H, dev)
+        if self.fused_tail and ops.dpt_tail_supported(y, dtype):
+            # upsample + position embedding + output_conv2 + activation in one launch (csrc/ovg_dpt_tail.h): the image-resolution maps stay on chip
+            return ops.dpt_tail(y, ph * ps, pw * ps, dtype, pos, P["oc2a"][0], P["oc2a"][1], P["oc2b"][0], P["oc2b"][1], head.activation)
+        y = ops.upsample(y, ph * ps, pw * ps, dtype, pos=pos)
         hmap = ops.conv(y, P["oc2a"][0], P["oc2a"][1], dtype, 32, ksize=3, relu=True, out_f32=True)
         return ops.dpt_out(hmap, P["oc2b"][0], P["oc2b"][1], head.activation)
 

@@ -14,7 +14,7 @@ OVG_BF16, OVG_F16, OVG_F32, OVG_F16X2 = 0, 1, 2, 3
 EPI_STORE, EPI_GELU, EPI_RES, EPI_PATCH = 0, 1, 2, 3
 OVG_MAX_SEG = 8
 KV_TILE = 64
-ABI_VERSION = 9
+ABI_VERSION = 10
 TILE_AUTO, TILE_128, TILE_256 = 0, 1, 2
 TILE_DMA_M, TILE_256M = 8, 10                                   # flag / 256 x 256 with the DMA requests inside the M sections
 TILE_256P = 4                                                  # persistent 256 x 256 (ovg_gemm256p.h): plain 16-bit dtypes, N % 256 == 0, K % 128 == 0
@@ -147,6 +147,12 @@ class DptOutParams(C.Structure):
     _fields_ = [("h", vp), ("w2", vp), ("b2", vp), ("val", vp), ("conf", vp), ("npix", i64), ("out_dim", i32), ("activation", i32)]
 
 
+class DptTailParams(C.Structure):
+    _fields_ = [("x", vp), ("ldx", i64), ("pos_x", vp), ("pos_y", vp), ("w1", vp), ("ldw1", i64), ("b1", vp), ("w2", vp), ("b2", vp),
+                ("val", vp), ("conf", vp), ("n_img", i64), ("H", i32), ("W", i32), ("OH", i32), ("OW", i32), ("C", i32),
+                ("out_dim", i32), ("activation", i32), ("dtype", i32)]
+
+
 class HeadsToTokensParams(C.Structure):
     _fields_ = [("x", vp), ("n_pad", i64), ("y", vp), ("ldy", i64), ("n", i64), ("heads", i32), ("dtype", i32)]
 
@@ -195,6 +201,7 @@ SYMBOLS = {
     "ovg_conv": (i32, [C.POINTER(ConvParams), vp]),
     "ovg_upsample": (i32, [C.POINTER(UpsampleParams), vp]),
     "ovg_dpt_out": (i32, [C.POINTER(DptOutParams), vp]),
+    "ovg_dpt_tail": (i32, [C.POINTER(DptTailParams), vp]),
     "ovg_unproject": (i32, [C.POINTER(UnprojectParams), vp]),
     "ovg_heads_to_tokens": (i32, [C.POINTER(HeadsToTokensParams), vp]),
     "ovg_probe_mfma": (i32, [vp, vp, vp, i32, vp]),

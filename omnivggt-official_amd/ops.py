@@ -405,6 +405,28 @@ def upsample(x, OH, OW, dtype, pos=None):
     return out
 
 
+def dpt_tail_supported(x, dtype):
+    """The one-launch output stage (ovg_dpt_tail) exists for the plain 16-bit dtypes and the model's 128-channel map."""
+    return dtype in (torch.bfloat16, torch.float16) and x.shape[-1] == 128
+
+
+def dpt_tail(x, OH, OW, dtype, pos, w1, b1, w2, b2, activation):
+    """x [n,H,W,128] dtype -> upsample to (OH, OW) + pos -> conv3x3(128->32)+ReLU -> conv1x1 -> activation: (val [n,OH,OW,od-1], conf [n,OH,OW]).
+    w1 [>=32, 9*128] dtype taps-major (the zero-padded matrix of the ovg_conv form is fine)."""
+    _chk_dev(x, w1, b1, w2, b2)
+    n, H, W, c = x.shape
+    od = w2.shape[0]
+    val = torch.empty(n, OH, OW, od - 1, device=x.device, dtype=torch.float32)
+    conf = torch.empty(n, OH, OW, device=x.device, dtype=torch.float32)
+    p = L.DptTailParams()
+    p.x, p.ldx, p.w1, p.ldw1, p.b1, p.w2, p.b2, p.val, p.conf = L.ptr(x), x.stride(2), L.ptr(w1), w1.stride(0), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(val), L.ptr(conf)
+    if pos is not None:
+        p.pos_x, p.pos_y = L.ptr(pos[0]), L.ptr(pos[1])
+    p.n_img, p.H, p.W, p.OH, p.OW, p.C, p.out_dim, p.activation, p.dtype = n, H, W, OH, OW, c, od, 0 if activation == "exp" else 1, L.dtype_code(dtype)
+    L.call("ovg_dpt_tail", p, _stream())
+    return val, conf
+
+
 def dpt_out(h, w2, b2, activation):
     """h f32 [n,H,W,32] (post-ReLU) -> (val [n,H,W,out_dim-1], conf [n,H,W]); activation 'exp' | 'inv_log'."""
     _chk_dev(h, w2, b2)

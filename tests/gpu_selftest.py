@@ -541,6 +541,30 @@ def test_heads(quick):
         rv, rc = emul.dpt_out(h, w2, b2, act)
         report("dpt_out_%s_val" % act, val, rv, 2e-5)
         report("dpt_out_%s_conf" % act, conf, rc, 2e-5)
+    # the one-launch output stage (ovg_dpt_tail, 16-bit dtypes): vs the emulated chain on the same 16-bit inputs, and vs the three-launch HIP form
+    # it replaces (ovg_upsample -> ovg_conv -> ovg_dpt_out); tiles cut by the image border in both directions, with / without the UV tables
+    for name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        for tag, n, H, W, OH, OW, od, act, pos in (("40to70_pos", 2, 40, 40, 70, 70, 2, "exp", True), ("ragged_53x47to75x61", 1, 53, 47, 75, 61, 4, "inv_log", False),
+                                                   ("296to518_pos", 1, 296, 296, 518, 518, 4, "inv_log", True)):
+            if quick and OH > 100:
+                continue
+            x = rnd(n, H, W, 128, g=g).to(dt)
+            w1 = torch.zeros(128, 9 * 128, dtype=dt)
+            w1[:32] = (rnd(32, 9 * 128, g=g) * (1.0 / (9 * 128) ** 0.5)).to(dt)
+            b1, w2, b2 = rnd(32, g=g) * 0.3, rnd(od, 32, g=g) * 0.2, rnd(od, g=g) * 0.1
+            ps = (rnd(OW, 64, g=g) * 0.1, rnd(OH, 64, g=g) * 0.1) if pos else None
+            psd = None if ps is None else (ps[0].to(DEV), ps[1].to(DEV))
+            xd, w1d, b1d, w2d, b2d = x.to(DEV), w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV)
+            val, conf = ops.dpt_tail(xd, OH, OW, dt, psd, w1d, b1d, w2d, b2d, act)
+            up = emul.upsample(x, OH, OW, dt, pos=ps)
+            rv, rc = emul.dpt_out(emul.conv(up, w1, b1, torch.float32, 32, ksize=3, relu=True, out_f32=True), w2, b2, act)
+            gate = 4e-3 if name == "bf16" else 5e-4
+            report("dpt_tail_%s_%s_val" % (tag, name), val, rv, gate)
+            report("dpt_tail_%s_%s_conf" % (tag, name), conf, rc, gate)
+            hmap = ops.conv(ops.upsample(xd, OH, OW, dt, pos=psd), w1d, b1d, dt, 32, ksize=3, relu=True, out_f32=True)
+            v3, c3 = ops.dpt_out(hmap, w2d, b2d, act)
+            report("dpt_tail_%s_%s_val_vs_three_launches" % (tag, name), val, v3, gate)
+            report("dpt_tail_%s_%s_conf_vs_three_launches" % (tag, name), conf, c3, gate)
     # whole head: HIP (16-bit) vs PyTorch f32 on CPU, S = 2
     for od, act in ((2, "exp"), (4, "inv_log")):
         torch.manual_seed(11 + od)

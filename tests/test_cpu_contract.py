@@ -57,7 +57,7 @@ def test_ctypes_struct_layout_matches_c():
              "ovg_block_params": L.BlockParams, "ovg_im2col_params": L.Im2colParams, "ovg_depth_stats_params": L.DepthStatsParams,
              "ovg_dino_specials_params": L.DinoSpecialsParams, "ovg_assemble_params": L.AssembleParams,
              "ovg_copy_rows_params": L.CopyRowsParams, "ovg_head_layernorm_params": L.HeadLayerNormParams,
-             "ovg_conv_params": L.ConvParams, "ovg_upsample_params": L.UpsampleParams, "ovg_dpt_out_params": L.DptOutParams,
+             "ovg_conv_params": L.ConvParams, "ovg_upsample_params": L.UpsampleParams, "ovg_dpt_out_params": L.DptOutParams, "ovg_dpt_tail_params": L.DptTailParams,
              "ovg_unproject_params": L.UnprojectParams, "ovg_heads_to_tokens_params": L.HeadsToTokensParams,
              "ovg_attn_merge_params": L.AttnMergeParams, "ovg_block_workspace": L.BlockWorkspace,
              "ovg_pack_weights_params": L.PackWeightsParams, "ovg_camera_block_weights": L.CameraBlockWeights,

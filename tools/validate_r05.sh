@@ -79,7 +79,7 @@ for stage in "$@"; do
     attn_st)    (timeout 900 python tests/gpu_selftest.py --only attn,attn_big,lse_merge,fallback 2>&1 | grep -v amdgpu.ids | grep -E "FAIL|SELFTEST|Error|error|Traceback|raise|fault|core|keytail|\(attn" | head -80) | tee "$O/attn_selftest.txt" ;;
     attn_ab8)   (timeout 900 python tests/bench_kernels.py attn --modes global --views ${OVG_AB_VIEWS:-8 9 10 12 13} --variants ${OVG_AB_VARIANTS:-0 50} --kv-splits ${OVG_AB_SPLITS:-0 1} --rounds 4 --target-ms 30 2>&1 | grep -v amdgpu.ids | tail -40) | tee "$O/attn_keytail_ab.txt" ;;
     ckpt)       (timeout 1500 python tools/validate_checkpoint.py --synthetic /tmp/ovg_synth_ckpt.safetensors --views 2 8 --aux --out "$O/checkpoint_rehearsal.json" 2>&1 | grep -v amdgpu.ids | tail -60) | tee "$O/checkpoint_rehearsal.txt"; rm -f /tmp/ovg_synth_ckpt.safetensors ;;
-    heads_st)   (timeout 900 python tests/gpu_selftest.py --only heads 2>&1 | grep -v amdgpu.ids | grep -E "FAIL|SELFTEST|Error|error|Traceback|raise|fault|core|c256|\(heads" | head -60) | tee "$O/heads_selftest.txt" ;;
+    heads_st)   (timeout 900 python tests/gpu_selftest.py --only heads 2>&1 | grep -v amdgpu.ids | grep -E "FAIL|SELFTEST|Error|error|Traceback|raise|fault|core|c256|dpt_tail|dpt_head|\(heads" | head -90) | tee "$O/heads_selftest.txt" ;;
     e2e)        for v in 8 64; do timeout 900 python bench.py --views $v --steps 4 --warmup 1 --no-cpu-baseline --no-parity --no-secondary 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('views', d['config']['views'], 'aggregator frames/s', d['value'], 'e2e', d.get('e2e'), d.get('e2e_error'))"; done 2>&1 | tee "$O/bench_e2e.txt" ;;
     prof_e2e8)  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_e2e_S8" -- python "$R/bench.py" --views 8 --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-secondary > "$O/prof_e2e_S8.log" 2>&1)
       f=$(find "$O/prof_e2e_S8" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$O/bench_e2e_S8_kernel_stats.csv" && head -16 "$f" | cut -c1-200
@@ -89,7 +89,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(list)
 for r in rows:
     n = r["Kernel_Name"]
-    if "conv" in n or "upsample" in n or "dpt_out" in n or "head_layernorm" in n:
+    if "conv" in n or "upsample" in n or "dpt_out" in n or "dpt_tail" in n or "head_layernorm" in n:
         agg[(n.split("(")[0][-60:], r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", ""))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 tot = sum(sum(v) for v in agg.values())
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
