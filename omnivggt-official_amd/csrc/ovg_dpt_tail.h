@@ -14,6 +14,10 @@
 // orders them) and finishes in registers: bias + ReLU, the 1x1 conv as 8 FMAs per output and lane + a 4-lane swap reduction, activation, store.
 #pragma once
 
+#ifndef OVG_DT_SKIP
+#define OVG_DT_SKIP 0      // lab builds (tools/probes/dpt_tail_probe.py): 1 = no MFMA phase, 2 = no interpolation phase, 4 = no tap prefetch
+#endif
+
 namespace dtail {
 
 constexpr int TH = 16, TW = 14, PR = TH + 2, PC = TW + 2;
@@ -154,6 +158,7 @@ __global__ __launch_bounds__(NT) void dpt_tail_kernel(ovg_dpt_tail_params p, flo
     int img, oy0, ox0;
     decode(t, img, oy0, ox0);
     // ---- phase 1: the upsampled patch (registers -> LDS). out = w00 a + w01 b + w10 c + w11 d + pos on the packed-f32 FMA
+#if !(OVG_DT_SKIP & 2)
     {
       int x0, x1; float lx;
       xgeo(ox0 + pc, x0, x1, lx);
@@ -186,11 +191,14 @@ __global__ __launch_bounds__(NT) void dpt_tail_kernel(ovg_dpt_tail_params p, flo
         *reinterpret_cast<u32x4*>(lds_dt + W_B + (pr * PC + pc) * 256 + ((ch ^ ((pc + 6 * pr) & 7)) << 4)) = o4;
       }
     }
+#endif
     __syncthreads();
     const int tn = t + gridDim.x;
+#if !(OVG_DT_SKIP & 4)
     if (tn < ntiles) prefetch(tn);                                            // in flight under phase 2
+#endif
 
-    if (wave < 7) {
+    if (wave < 7 && !(OVG_DT_SKIP & 1)) {
       // ---- phase 2: 3x3 convolution on the matrix pipe. B fragment of (tap, 32-channel group kc), block b: patch pixel p0 + tap shift,
       // chunk (4 kc + g) ^ fs with fs = the pixel's swizzle class = ((g ^ fs) & 3) | ((kc ^ (fs >> 2)) << 2): one XOR per read (byte offset kc << 6)
       int q0[2] = {p0[0], p0[1]}, qf[2] = {f0[0], f0[1]};

@@ -36,8 +36,12 @@ except Exception:  # pragma: no cover - optional
 class OmniVGGT(nn.Module, _HubMixin):
     def __init__(self, img_size=518, patch_size=14, embed_dim=1024, depth=24, dino_depth=24,
                  compute_dtype=torch.float32, dpt_layers=(4, 11, 17, 23), hip_heads=True, hip_camera_head=True, hip_heads_f32=True,
-                 head_dtype=None):
+                 head_dtype=None, dpt_frames_chunk=64):
         super().__init__()
+        # frames per pass of the HIP DPT heads. The reference walks the views in chunks of 8 (dpt_head.py:133,163) to bound activation memory on
+        # 24-80 GB parts; per-frame results do not depend on the chunking, the 288 GB of an MI355X hold 64 frames of head activations (~17 GB in
+        # bf16), and the level-3 / level-4 convolutions (19^2 and 37^2 pixels per frame) only fill the chip from a few dozen frames on
+        self.dpt_frames_chunk = dpt_frames_chunk
         # head_dtype: None = the heads follow the aggregator's compute dtype (bf16 / f16 heads in the 16-bit modes, exact-f32 heads in the
         # f32 and split-f16 modes); torch.float32 = always the exact-f32 HIP heads, i.e. the reference's own arrangement (it disables
         # autocast around the heads, omnivggt.py:45) at ~5x the heads' time -- README "16-bit heads" has the error table behind the default
@@ -69,7 +73,7 @@ class OmniVGGT(nn.Module, _HubMixin):
     def _dpt(self, which, head, tokens, imgs32, patch_start_idx):
         dt = self.head_dtype or L.head_dtype(self.aggregator.compute_dtype)
         if self.hip_heads and imgs32.is_cuda and (dt in (torch.bfloat16, torch.float16) or self.hip_heads_f32):
-            return self._hip_dpt[which](tokens, imgs32, patch_start_idx, dtype=dt)     # f32: exact-f32 MFMA convolutions (r03)
+            return self._hip_dpt[which](tokens, imgs32, patch_start_idx, frames_chunk_size=self.dpt_frames_chunk, dtype=dt)   # f32: exact-f32 MFMA convolutions (r03)
         return head(tokens, images=imgs32, patch_start_idx=patch_start_idx)
 
     def set_compute_dtype(self, dtype):

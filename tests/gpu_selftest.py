@@ -587,6 +587,10 @@ def test_heads(quick):
                 gate = {"bf16": 4e-2, "f16": 6e-3, "f32": 1e-4}[name]
                 report("dpt_head_%s_%s_val" % (act, name), val, rv, gate)
                 report("dpt_head_%s_%s_conf" % (act, name), conf, rc, gate)
+            # per-frame results do not depend on how many frames a pass takes (model.dpt_frames_chunk: 64 on this part, 8 in the reference)
+            v1, c1 = hip(toks_d, images.to(DEV), 5, frames_chunk_size=1, dtype=torch.bfloat16)
+            v2, c2 = hip(toks_d, images.to(DEV), 5, frames_chunk_size=2, dtype=torch.bfloat16)
+            report("dpt_head_%s_bf16_frame_chunking_is_bit_invariant" % act, torch.cat([v1.flatten(), c1.flatten()]), torch.cat([v2.flatten(), c2.flatten()]), 0.0)
             if quick:
                 break
 
