@@ -36,8 +36,13 @@ except Exception:  # pragma: no cover - optional
 class OmniVGGT(nn.Module, _HubMixin):
     def __init__(self, img_size=518, patch_size=14, embed_dim=1024, depth=24, dino_depth=24,
                  compute_dtype=torch.float32, dpt_layers=(4, 11, 17, 23), hip_heads=True, hip_camera_head=True, hip_heads_f32=True,
-                 head_dtype=None, dpt_frames_chunk=64):
+                 head_dtype=None, dpt_frames_chunk=64, concurrent_heads=True):
         super().__init__()
+        # the three heads are independent given the aggregator's tokens: on one GPU they run on three side streams (forked from / joined to the
+        # caller's stream), so the camera head's ~250 tiny launches and the level-3 / level-4 convolutions of the two DPT heads (46-184 workgroups
+        # on 256 CUs) overlap instead of queueing behind each other. Results are bit-identical to the sequential order.
+        self.concurrent_heads = concurrent_heads
+        self._head_streams = {}
         # frames per pass of the HIP DPT heads. The reference walks the views in chunks of 8 (dpt_head.py:133,163) to bound activation memory on
         # 24-80 GB parts; per-frame results do not depend on the chunking, the 288 GB of an MI355X hold 64 frames of head activations (~17 GB in
         # bf16), and the level-3 / level-4 convolutions (19^2 and 37^2 pixels per frame) only fill the chip from a few dozen frames on
@@ -61,6 +66,28 @@ class OmniVGGT(nn.Module, _HubMixin):
         # state-dict keys stay those of point_head / depth_head
         self._hip_dpt = {"point": HipDPTHead(self.point_head), "depth": HipDPTHead(self.depth_head)}
         self._hip_cam = HipCameraHead(self.camera_head)
+
+    def _run_heads(self, jobs, concurrent):
+        """Run the head closures; concurrently = each on its own side stream between a fork event and a join on the caller's stream."""
+        if not concurrent or len(jobs) < 2:
+            return {name: fn() for name, fn in jobs}
+        cur = torch.cuda.current_stream()
+        dev = cur.device
+        streams = self._head_streams.setdefault(str(dev), [torch.cuda.Stream(device=dev) for _ in range(3)])
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        res = {}
+        for (name, fn), st in zip(jobs, streams):
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                res[name] = fn()
+        for _, st in zip(jobs, streams):
+            cur.wait_stream(st)
+        for val in res.values():                       # the outputs were allocated on a side stream and live on on the caller's
+            for t in val:
+                if torch.is_tensor(t):
+                    t.record_stream(cur)
+        return res
 
     def _camera(self, cam_tokens):
         dt = self.head_dtype or L.head_dtype(self.aggregator.compute_dtype)      # split-f16 aggregator: the heads run on the exact-f32 kernels
@@ -160,13 +187,20 @@ class OmniVGGT(nn.Module, _HubMixin):
                 lo, hi = parts[shard.rank]
                 cam_tokens = [shard.gather_views(tokens[-1][:, :, :1].contiguous(), parts)]
                 imgs32 = imgs32[:, lo:hi]
+            jobs = []
             if self.camera_head is not None:
-                poses = self._camera(cam_tokens)
-                out["pose_enc"], out["pose_enc_list"] = poses[-1], poses
+                jobs.append(("camera", lambda: self._camera(cam_tokens)))
             if self.depth_head is not None:
-                out["depth"], out["depth_conf"] = self._dpt("depth", self.depth_head, tokens, imgs32, patch_start_idx)
+                jobs.append(("depth", lambda: self._dpt("depth", self.depth_head, tokens, imgs32, patch_start_idx)))
             if self.point_head is not None:
-                out["world_points"], out["world_points_conf"] = self._dpt("point", self.point_head, tokens, imgs32, patch_start_idx)
+                jobs.append(("point", lambda: self._dpt("point", self.point_head, tokens, imgs32, patch_start_idx)))
+            res = self._run_heads(jobs, concurrent=self.concurrent_heads and self.hip_heads and not sharded and imgs32.is_cuda)
+            if "camera" in res:
+                out["pose_enc"], out["pose_enc_list"] = res["camera"][-1], res["camera"]
+            if "depth" in res:
+                out["depth"], out["depth_conf"] = res["depth"]
+            if "point" in res:
+                out["world_points"], out["world_points_conf"] = res["point"]
             if sharded:
                 for key in ("depth", "depth_conf", "world_points", "world_points_conf"):
                     if key in out:
