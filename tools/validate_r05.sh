@@ -35,6 +35,7 @@ for stage in "$@"; do
       python tools/traffic_json.py --views 8 "$P"/attn_S8_pmc3 "$P"/attn_S8_pmc4 --views 64 "$P"/attn_S64_pmc3 "$P"/attn_S64_pmc4 --out "$O/traffic.json" \
         --source "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum / WRITE_SIZE TCC_MISS_sum passes (tools/validate_r05.sh traffic_only) of the shipped global-attention launches; PMC counters cannot be read from inside bench.py, so the figure is not re-measured in the bench run" > "$O/traffic_json.log" 2>&1
       python -c "import json; d=json.load(open('$O/traffic.json')); print('traffic', d['attention_source_digest'][:12], d['global_attn_S64_bytes_per_launch'], d['global_attn_S8_bytes_per_launch'])"
+      cp "$O/traffic.json" "$R/profiles/traffic.json"       # the bench stage of the same pass reads the record taken on THIS tree
       find "$P" -name "*.csv" -size +1M -delete ;;
     attn_ab)    (timeout 900 python tools/probes/attn_ab_probe.py ${OVG_AB_ARGS:-} 2>&1 | grep -v amdgpu.ids | tail -30) | tee "$O/attn_ab.txt" ;;
     configs)    # the other BASELINE configs + end-to-end lines (aggregator + three heads), one JSON line each
@@ -81,9 +82,11 @@ for stage in "$@"; do
     ckpt)       (timeout 1500 python tools/validate_checkpoint.py --synthetic /tmp/ovg_synth_ckpt.safetensors --views 2 8 --aux --out "$O/checkpoint_rehearsal.json" 2>&1 | grep -v amdgpu.ids | tail -60) | tee "$O/checkpoint_rehearsal.txt"; rm -f /tmp/ovg_synth_ckpt.safetensors ;;
     heads_st)   (timeout 900 python tests/gpu_selftest.py --only heads 2>&1 | grep -v amdgpu.ids | grep -E "FAIL|SELFTEST|Error|error|Traceback|raise|fault|core|c256|dpt_tail|dpt_head|\(heads" | head -90) | tee "$O/heads_selftest.txt" ;;
     e2e)        for v in 8 64; do timeout 900 python bench.py --views $v --steps 4 --warmup 1 --no-cpu-baseline --no-parity --no-secondary 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('views', d['config']['views'], 'aggregator frames/s', d['value'], 'e2e', d.get('e2e'), d.get('e2e_error'))"; done 2>&1 | tee "$O/bench_e2e.txt" ;;
-    prof_e2e8)  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_e2e_S8" -- python "$R/bench.py" --views 8 --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-secondary > "$O/prof_e2e_S8.log" 2>&1)
-      f=$(find "$O/prof_e2e_S8" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$O/bench_e2e_S8_kernel_stats.csv" && head -16 "$f" | cut -c1-200
-      t=$(find "$O/prof_e2e_S8" -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python - "$t" <<'PY' | tee "$O/conv_launches_S8.txt"
+    prof_e2e8|prof_e2e64)
+      ev=${stage#prof_e2e}
+      (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_e2e_S$ev" -- python "$R/bench.py" --views $ev --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-secondary > "$O/prof_e2e_S$ev.log" 2>&1)
+      f=$(find "$O/prof_e2e_S$ev" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$O/bench_e2e_S${ev}_kernel_stats.csv" && head -16 "$f" | cut -c1-200
+      t=$(find "$O/prof_e2e_S$ev" -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python - "$t" <<'PY' | tee "$O/conv_launches_S$ev.txt"
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(list)
@@ -95,7 +98,7 @@ tot = sum(sum(v) for v in agg.values())
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     print("%-62s grid %-9s calls %3d  avg %9.1f us  total %9.1f us  %5.1f %%" % (k[0], k[1], len(v), sum(v) / len(v), sum(v), 100 * sum(v) / tot))
 PY
-      find "$O/prof_e2e_S8" -name "*.csv" -size +1M -delete ;;
+      find "$O/prof_e2e_S$ev" -name "*.csv" -size +1M -delete ;;
     pmc_lite)   # SQ / GRBM counter passes on the shipped bf16 attention and GEMM launches (own runs, only --kernel-trace next to --pmc)
       P=$O/prof_pmc; mkdir -p "$P"
       (cd /tmp && export TMPDIR=/tmp
