@@ -193,7 +193,6 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the f32-mode cross-check of the timed outputs (N=1)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 8-view secondary measurement (N=1)")
     ap.add_argument("--torch-heads", action="store_true", help="with --e2e: run the DPT heads as f32 PyTorch modules instead of the HIP kernels")
-    ap.add_argument("--dpt-fine-chunk", type=int, default=0, help="e2e: frames per pass of the fine (74^2 and up) part of the DPT heads (0 = the model default, 8)")
     ap.add_argument("--e2e-views", type=int, default=0, help="view count of the end-to-end measurement (default: the timed view count, and 8 views next to the secondary)")
     ap.add_argument("--e2e", action="store_true", help="(default since round 5; kept for old command lines) also time the whole OmniVGGT.forward")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end measurement (aggregator + camera head + both DPT heads; N = 1)")
@@ -456,9 +455,6 @@ def main():
                 inp = synthetic_inputs(Se, dev, aux=args.aux)
                 idx = list(range(Se)) if args.aux else []
                 model.hip_heads = not args.torch_heads
-                if args.dpt_fine_chunk:
-                    for h in model._hip_dpt.values():
-                        h.fine_chunk = args.dpt_fine_chunk
                 full = lambda: model(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], idx, idx)
                 full()
                 full()
@@ -471,7 +467,7 @@ def main():
                 torch_heads = args.torch_heads or (hd == "f32" and not model.hip_heads_f32)
                 return {"views": Se, "frames_per_s": round(Se / ms * 1e3, 3), "ms_per_forward": round(ms, 3), "forwards_timed": reps,
                         "dpt_heads": "pytorch-f32" if torch_heads else "hip-" + hd, "camera_head": "pytorch-f32" if torch_heads else "hip-" + hd,
-                        "heads": "three side streams, DPT passes of %d frames (coarse levels) / %d (74^2 and up), one-launch output stage" % (model.dpt_frames_chunk, model._hip_dpt["depth"].fine_chunk) if not torch_heads else "sequential"}
+                        "heads": "three side streams, %d frames per DPT pass, one-launch output stage" % model.dpt_frames_chunk if not torch_heads else "sequential"}
             try:
                 wd.stage("end-to-end forward (aggregator + three heads)")
                 Se = args.e2e_views or S

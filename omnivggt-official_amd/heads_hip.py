@@ -51,7 +51,6 @@ class HipDPTHead:
         self._packed = None
         self._key = None
         self._pos = {}
-        self.fine_chunk = 8          # frames per pass of the 74^2-and-finer part of a head (see _chunk)
         self.fused_tail = True       # False: the three-launch output stage (ovg_upsample -> ovg_conv -> ovg_dpt_out), kept for A/B and the f32 modes
 
     # -- weights ---------------------------------------------------------------------------------
@@ -121,20 +120,13 @@ class HipDPTHead:
         return ops.conv(t, w2, b2, dtype, 256, ksize=3, add1=x, add2=add2, relu=relu_out)
 
     def _chunk(self, toks, b, s0, s1, H, W, start, dtype):
-        """One pass over frames [s0, s1) of batch entry b, in two grains (per-frame results do not depend on either):
-        COARSE (all frames of the pass): the 37^2 / 19^2 side -- LayerNorm, the four projections, the stride-2 resize, layer3_rn / layer4_rn,
-        refinenet4 and refinenet3 -- whose convolutions have 361 / 1369 pixels per frame and only fill the chip from dozens of frames on
-        (64 views: 137 us per launch at 19^2 against 8 x 77 us in passes of 8, 260 us against 8 x 68 us at 37^2);
-        FINE (`fine_chunk` frames at a time, the reference's chunk of 8): everything at 74^2 and above, where 8 frames already are several rounds
-        of the chip and a pass of 64 frames would only hold 8x the activations (22 MB per frame and tensor at 296^2) for the same time
-        (measured, 64 views end to end: fine passes of 8 / 16 / 64 frames within 0.3 % of each other)."""
         head = self.head
         n, ps = s1 - s0, head.patch_size
         ph, pw = H // ps, W // ps
         dev = toks[0].device
         P = self._weights(dtype, dev)
         oc = [m.weight.shape[0] for m in head.projects]
-        proj = []
+        pyramid = []
         for i, layer in enumerate(head.intermediate_layer_idx):
             t = toks[layer][b, s0:s1]                                   # [n, tokens, 2C] f32 view
             tpv = t.shape[1]
@@ -142,49 +134,35 @@ class HipDPTHead:
                                    tokens_per_view=tpv, n_special=start)
             x = x.view(n, ph, pw, -1)
             w, bias = P["proj"][i]
-            proj.append(ops.conv(x, w, bias, dtype, oc[i], ksize=1, pos=self._postab(oc[i], ph, pw, W, H, dev)))
+            x = ops.conv(x, w, bias, dtype, oc[i], ksize=1, pos=self._postab(oc[i], ph, pw, W, H, dev))
+            if i == 0:
+                x = ops.conv(x, P["up0"][0], P["up0"][1], dtype, oc[0], ksize=1, upshuffle=4)
+            elif i == 1:
+                x = ops.conv(x, P["up1"][0], P["up1"][1], dtype, oc[1], ksize=1, upshuffle=2)
+            elif i == 3:
+                x = ops.conv(x, P["down3"][0], P["down3"][1], dtype, oc[3], ksize=3, stride=2)
+            # layerN_rn (no bias); its only consumers open with the in-place ReLU -> emit relu(x)
+            pyramid.append(ops.conv(x, P["rn"][i], None, dtype, 256, ksize=3, relu=True))
+
         F = P["fusion"]
-        # layerN_rn (no bias); its only consumers open with the in-place ReLU -> emit relu(x)
-        p2 = ops.conv(proj[2], P["rn"][2], None, dtype, 256, ksize=3, relu=True)
-        x3 = ops.conv(proj[3], P["down3"][0], P["down3"][1], dtype, oc[3], ksize=3, stride=2)
-        p3 = ops.conv(x3, P["rn"][3], None, dtype, 256, ksize=3, relu=True)
         # refinenet4: no skip
-        u = self._rcu(F[4]["rcu2"], p3, dtype)
+        u = self._rcu(F[4]["rcu2"], pyramid[3], dtype)
         u = ops.conv(u, F[4]["out"][0], F[4]["out"][1], dtype, 256, ksize=1)
-        y = ops.upsample(u, p2.shape[1], p2.shape[2], dtype)
-        xs = self._rcu(F[3]["rcu1"], p2, dtype, add2=y, relu_out=True)             # relu(y + RCU1(skip))
-        u = self._rcu(F[3]["rcu2"], xs, dtype)
-        u3 = ops.conv(u, F[3]["out"][0], F[3]["out"][1], dtype, 256, ksize=1)     # refinenet3 before its resize (1x1 conv and resize commute)
-        del proj[2:], x3, p2, p3, xs, u, y
-        fine = n if (not self.fine_chunk or self.fine_chunk >= n) else self.fine_chunk
+        y = ops.upsample(u, pyramid[2].shape[1], pyramid[2].shape[2], dtype)
+        for lvl, skip, size in ((3, pyramid[2], pyramid[1].shape[1:3]), (2, pyramid[1], pyramid[0].shape[1:3]),
+                                (1, pyramid[0], (2 * pyramid[0].shape[1], 2 * pyramid[0].shape[2]))):
+            xs = self._rcu(F[lvl]["rcu1"], skip, dtype, add2=y, relu_out=True)      # relu(y + RCU1(skip))
+            u = self._rcu(F[lvl]["rcu2"], xs, dtype)
+            u = ops.conv(u, F[lvl]["out"][0], F[lvl]["out"][1], dtype, 256, ksize=1)
+            y = ops.upsample(u, size[0], size[1], dtype)
+        y = ops.conv(y, P["oc1"][0], P["oc1"][1], dtype, 128, ksize=3)
         pos = self._postab(128, ph * ps, pw * ps, W, H, dev)
-        vals, confs = [], []
-        for f0 in range(0, n, fine):
-            f1 = min(f0 + fine, n)
-            x0 = ops.conv(proj[0][f0:f1], P["up0"][0], P["up0"][1], dtype, oc[0], ksize=1, upshuffle=4)
-            p0 = ops.conv(x0, P["rn"][0], None, dtype, 256, ksize=3, relu=True)
-            x1 = ops.conv(proj[1][f0:f1], P["up1"][0], P["up1"][1], dtype, oc[1], ksize=1, upshuffle=2)
-            p1 = ops.conv(x1, P["rn"][1], None, dtype, 256, ksize=3, relu=True)
-            del x0, x1
-            y = ops.upsample(u3[f0:f1], p1.shape[1], p1.shape[2], dtype)
-            for lvl, skip, size in ((2, p1, p0.shape[1:3]), (1, p0, (2 * p0.shape[1], 2 * p0.shape[2]))):
-                xs = self._rcu(F[lvl]["rcu1"], skip, dtype, add2=y, relu_out=True)
-                u = self._rcu(F[lvl]["rcu2"], xs, dtype)
-                u = ops.conv(u, F[lvl]["out"][0], F[lvl]["out"][1], dtype, 256, ksize=1)
-                y = ops.upsample(u, size[0], size[1], dtype)
-            y = ops.conv(y, P["oc1"][0], P["oc1"][1], dtype, 128, ksize=3)
-            if self.fused_tail and ops.dpt_tail_supported(y, dtype):
-                # upsample + position embedding + output_conv2 + activation in one launch (csrc/ovg_dpt_tail.h): the image-resolution maps stay on chip
-                v, c = ops.dpt_tail(y, ph * ps, pw * ps, dtype, pos, P["oc2a"][0], P["oc2a"][1], P["oc2b"][0], P["oc2b"][1], head.activation)
-            else:
-                y = ops.upsample(y, ph * ps, pw * ps, dtype, pos=pos)
-                hmap = ops.conv(y, P["oc2a"][0], P["oc2a"][1], dtype, 32, ksize=3, relu=True, out_f32=True)
-                v, c = ops.dpt_out(hmap, P["oc2b"][0], P["oc2b"][1], head.activation)
-            vals.append(v)
-            confs.append(c)
-        if len(vals) == 1:
-            return vals[0], confs[0]
-        return torch.cat(vals, 0), torch.cat(confs, 0)
+        if self.fused_tail and ops.dpt_tail_supported(y, dtype):
+            # upsample + position embedding + output_conv2 + activation in one launch (csrc/ovg_dpt_tail.h): the image-resolution maps stay on chip
+            return ops.dpt_tail(y, ph * ps, pw * ps, dtype, pos, P["oc2a"][0], P["oc2a"][1], P["oc2b"][0], P["oc2b"][1], head.activation)
+        y = ops.upsample(y, ph * ps, pw * ps, dtype, pos=pos)
+        hmap = ops.conv(y, P["oc2a"][0], P["oc2a"][1], dtype, 32, ksize=3, relu=True, out_f32=True)
+        return ops.dpt_out(hmap, P["oc2b"][0], P["oc2b"][1], head.activation)
 
 
 class HipCameraHead:

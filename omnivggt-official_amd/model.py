@@ -36,7 +36,7 @@ except Exception:  # pragma: no cover - optional
 class OmniVGGT(nn.Module, _HubMixin):
     def __init__(self, img_size=518, patch_size=14, embed_dim=1024, depth=24, dino_depth=24,
                  compute_dtype=torch.float32, dpt_layers=(4, 11, 17, 23), hip_heads=True, hip_camera_head=True, hip_heads_f32=True,
-                 head_dtype=None, dpt_frames_chunk=64, dpt_fine_chunk=8, concurrent_heads=True):
+                 head_dtype=None, dpt_frames_chunk=64, concurrent_heads=True):
         super().__init__()
         # the three heads are independent given the aggregator's tokens: on one GPU they run on three side streams (forked from / joined to the
         # caller's stream), so the camera head's ~250 tiny launches and the level-3 / level-4 convolutions of the two DPT heads (46-184 workgroups
@@ -65,8 +65,6 @@ class OmniVGGT(nn.Module, _HubMixin):
         # HIP front ends of the two DPT heads; plain objects (not sub-modules): the parameters and the
         # state-dict keys stay those of point_head / depth_head
         self._hip_dpt = {"point": HipDPTHead(self.point_head), "depth": HipDPTHead(self.depth_head)}
-        for h in self._hip_dpt.values():
-            h.fine_chunk = dpt_fine_chunk       # frames per pass of the 74^2-and-finer part (heads_hip.HipDPTHead._chunk)
         self._hip_cam = HipCameraHead(self.camera_head)
 
     def _run_heads(self, jobs, concurrent):
