@@ -116,7 +116,8 @@ __global__ __launch_bounds__(NT) void dpt_tail_kernel(ovg_dpt_tail_params p, flo
     // position-embedding rows of the tile: entry e = tid (+ 512): row e / 16 of the table (16 columns then 18 rows), 4 floats at (e % 16) * 4
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int e = tid + NT * k;
+      int e = tid + NT * k;
+      asm volatile("" : "+v"(e));                       // per-tile opaque: keeps the 64-bit table addresses from being hoisted out of the tile loop (and spilled)
       pp[k] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (p.pos_x && e < POS_ROWS * 16) {
         const int row = e >> 4, c4 = (e & 15) * 4;
