@@ -100,6 +100,29 @@ def test_argument_validation_without_gpu():
         want32 = 2 * r(S * 2048 * 4) + r(S * 9 * 4) + r(S * 32768 * 4) + 3 * r(S * 2048 * 4) + r(S * 6144 * 4) + r(S * 8192 * 4)
         assert lib.ovg_camera_head_workspace_bytes(S, L.OVG_F32) == want32       # f32 parity mode: f32 activation buffers
     assert lib.ovg_camera_head_workspace_bytes(8, 99) == -1 and lib.ovg_camera_head_workspace_bytes(0, L.OVG_BF16) == -1
+    # ovg_dpt_tail (ABI 10): NULL / bad shapes are OVG_E_ARG, a dtype or channel count it has no kernel for is OVG_E_UNSUPPORTED (the host
+    # then runs the three-launch form) -- all decided before the device is touched
+    assert lib.ovg_dpt_tail(None, None) == -1 and lib.ovg_dpt_tail(ctypes.byref(L.DptTailParams()), None) == -1
+    fake = 0x10000
+    t = L.DptTailParams()
+    t.x, t.w1, t.w2, t.b2, t.val, t.conf = fake, fake, fake, fake, fake, fake
+    t.ldx, t.ldw1, t.n_img, t.H, t.W, t.OH, t.OW, t.C, t.out_dim, t.activation, t.dtype = 128, 1152, 1, 296, 296, 518, 518, 128, 4, 1, L.OVG_F32
+    assert lib.ovg_dpt_tail(ctypes.byref(t), None) == -4                        # f32: three launches
+    t.dtype = L.OVG_F16X2
+    assert lib.ovg_dpt_tail(ctypes.byref(t), None) == -4
+    t.dtype, t.C, t.ldx = L.OVG_BF16, 256, 256
+    assert lib.ovg_dpt_tail(ctypes.byref(t), None) == -4                        # not the model's 128-channel map
+    t.C, t.ldx, t.out_dim = 128, 128, 5
+    assert lib.ovg_dpt_tail(ctypes.byref(t), None) == -1
+    t.out_dim, t.pos_x = 4, fake                                                # pos_x without pos_y
+    assert lib.ovg_dpt_tail(ctypes.byref(t), None) == -1
+    t.pos_x, t.ldw1 = None, 1000                                                # weight rows shorter than 9 * C
+    assert lib.ovg_dpt_tail(ctypes.byref(t), None) == -1
+    t.ldw1, t.dtype = 1152, 7
+    assert lib.ovg_dpt_tail(ctypes.byref(t), None) == -2
+    from omnivggt_official_amd import ops
+    assert ops.dpt_tail_supported(torch.empty(1, 4, 4, 128), torch.bfloat16) and not ops.dpt_tail_supported(torch.empty(1, 4, 4, 128), torch.float32)
+    assert not ops.dpt_tail_supported(torch.empty(1, 4, 4, 256), torch.float16) and not ops.dpt_tail_supported(torch.empty(1, 4, 4, 128), L.F32X)
 
 
 def test_split_f16_mode_contract_on_cpu():
@@ -526,3 +549,16 @@ def test_attention_launch_plan_of_the_baseline_shapes():
     assert (pr["splits"], pr["q_tile"], pr["tail_q_tile"]) == (4, 256, 0) and pr["part_bytes"] == 4 * 16 * ops.pad_to(8 * P, 64) * 64 * 4
     # a forced factor is honoured and sized; the baseline kernel (variant 1) never splits
     assert plan(16, 8 * P, [8 * P], bf, kv_splits=3)["splits"] == 3 and plan(16, 8 * P, [8 * P], bf, variant=1)["splits"] == 1
+
+
+def test_heads_run_in_order_when_not_concurrent():
+    """OmniVGGT._run_heads: without a device (or with one job / in the sharded run) the head closures run in the reference's order
+    on the caller's stream; the side-stream form needs a GPU (tests/test_gpu_aggregator.py exercises it through the model forward)."""
+    from omnivggt_official_amd.model import OmniVGGT
+    calls = []
+    jobs = [("camera", lambda: calls.append("camera") or ["pose"]), ("depth", lambda: calls.append("depth") or ("d", "dc")),
+            ("point", lambda: calls.append("point") or ("p", "pc"))]
+    res = OmniVGGT._run_heads(object(), jobs, concurrent=False)
+    assert calls == ["camera", "depth", "point"] and res == {"camera": ["pose"], "depth": ("d", "dc"), "point": ("p", "pc")}
+    calls.clear()
+    assert OmniVGGT._run_heads(object(), jobs[:1], concurrent=True) == {"camera": ["pose"]} and calls == ["camera"]   # one job: nothing to overlap
