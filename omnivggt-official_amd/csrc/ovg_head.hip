@@ -446,6 +446,7 @@ extern "C" int ovg_dpt_tail(const ovg_dpt_tail_params* p, void* stream) {
   if ((p->pos_x == nullptr) != (p->pos_y == nullptr)) return OVG_E_ARG;
   if (p->dtype != OVG_BF16 && p->dtype != OVG_F16) return p->dtype == OVG_F32 || p->dtype == OVG_F16X2 ? OVG_E_UNSUPPORTED : OVG_E_DTYPE;
   if (p->C != dtail::CI) return OVG_E_UNSUPPORTED;
+  if ((int64_t)p->H * p->W * p->ldx >= ((int64_t)1 << 31)) return OVG_E_UNSUPPORTED;   // the kernel indexes one source image with 32-bit element offsets
   if (p->ldx < p->C || (p->ldx % 8) || p->ldw1 < 9 * p->C || (p->ldw1 % 8) || !al16(p->x) || !al16(p->w1)) return OVG_E_ARG;
   if ((p->pos_x && (!al16(p->pos_x) || !al16(p->pos_y))) || (p->b1 && !al16(p->b1))) return OVG_E_ARG;
   const int tiles_x = (p->OW + dtail::TW - 1) / dtail::TW, tiles_y = (p->OH + dtail::TH - 1) / dtail::TH;
