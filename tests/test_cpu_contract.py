@@ -562,3 +562,35 @@ def test_heads_run_in_order_when_not_concurrent():
     assert calls == ["camera", "depth", "point"] and res == {"camera": ["pose"], "depth": ("d", "dc"), "point": ("p", "pc")}
     calls.clear()
     assert OmniVGGT._run_heads(object(), jobs[:1], concurrent=True) == {"camera": ["pose"]} and calls == ["camera"]   # one job: nothing to overlap
+
+
+def test_dpt_tail_patch_swizzle_is_conflict_free_and_consistent():
+    """csrc/ovg_dpt_tail.h keeps an 18 x 16-pixel patch in LDS with 256-byte pixels whose 16-byte chunks are XOR-swizzled by the pixel's
+    class (col + 6 row) & 7. Host restatement of the kernel's address arithmetic (tile constants parsed from the header): (i) the one-XOR form the
+    matrix phase uses equals the direct formula (chunk ^ class), (ii) the class the reader derives per tap equals the class the writer stored
+    under, (iii) every 8 consecutive lanes of every B-fragment read (16 consecutive tile pixels, 14-wide rows, any tap, any channel group) hit
+    8 different 16-byte bank groups."""
+    import re
+    src = open(os.path.join(ROOT, "omnivggt-official_amd", "csrc", "ovg_dpt_tail.h")).read()
+    m = re.search(r"constexpr int TH = (\d+), TW = (\d+), PR = TH \+ 2, PC = TW \+ 2;", src)
+    TH, TW = int(m.group(1)), int(m.group(2))
+    PC = TW + 2
+    assert (TH * TW) % 16 == 0 and "(pc + 6 * pr) & 7" in src and "(mx[b] + 6 * my[b]) & 7" in src
+    for mb in range(TH * TW // 16):
+        for ky in range(3):
+            for kx in range(3):
+                for kc in range(4):
+                    addrs = []
+                    for lane in range(64):
+                        g, lr = lane >> 4, lane & 15
+                        pix = 16 * mb + lr
+                        y, x = divmod(pix, TW)
+                        p0, f0 = y * PC + x, (x + 6 * y) & 7
+                        fs = (f0 + kx + 6 * ky) & 7
+                        assert fs == ((x + kx) + 6 * (y + ky)) & 7                                   # reader's class == writer's class of that patch pixel
+                        tbx = ((p0 + ky * PC + kx) * 256 + (((g ^ fs) & 3) << 4)) ^ ((fs & 4) << 4)
+                        a = tbx ^ (kc << 6)
+                        assert a == (p0 + ky * PC + kx) * 256 + (((4 * kc + g) ^ fs) << 4)
+                        addrs.append(a)
+                    for s in range(0, 64, 8):
+                        assert len({(a // 16) % 8 for a in addrs[s:s + 8]}) == 8, (mb, ky, kx, kc, s)
