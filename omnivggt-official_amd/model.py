@@ -33,6 +33,9 @@ except Exception:  # pragma: no cover - optional
         pass
 
 
+_HEAD_STREAMS = {}
+
+
 class OmniVGGT(nn.Module, _HubMixin):
     def __init__(self, img_size=518, patch_size=14, embed_dim=1024, depth=24, dino_depth=24,
                  compute_dtype=torch.float32, dpt_layers=(4, 11, 17, 23), hip_heads=True, hip_camera_head=True, hip_heads_f32=True,
@@ -42,7 +45,6 @@ class OmniVGGT(nn.Module, _HubMixin):
         # caller's stream), so the camera head's ~250 tiny launches and the level-3 / level-4 convolutions of the two DPT heads (46-184 workgroups
         # on 256 CUs) overlap instead of queueing behind each other. Results are bit-identical to the sequential order.
         self.concurrent_heads = concurrent_heads
-        self._head_streams = {}
         # frames per pass of the HIP DPT heads. The reference walks the views in chunks of 8 (dpt_head.py:133,163) to bound activation memory on
         # 24-80 GB parts; per-frame results do not depend on the chunking, the 288 GB of an MI355X hold 64 frames of head activations (~17 GB in
         # bf16), and the level-3 / level-4 convolutions (19^2 and 37^2 pixels per frame) only fill the chip from a few dozen frames on
@@ -73,7 +75,7 @@ class OmniVGGT(nn.Module, _HubMixin):
             return {name: fn() for name, fn in jobs}
         cur = torch.cuda.current_stream()
         dev = cur.device
-        streams = self._head_streams.setdefault(str(dev), [torch.cuda.Stream(device=dev) for _ in range(3)])
+        streams = _HEAD_STREAMS.setdefault(str(dev), [torch.cuda.Stream(device=dev) for _ in range(3)])   # per device, shared by all models of the process (not model state: nothing to copy / pickle)
         fork = torch.cuda.Event()
         fork.record(cur)
         res = {}
