@@ -182,6 +182,37 @@ def self_launch(n, argv, script=None, timeout=None):
         return 124
 
 
+RCCL_LOG = os.path.join(os.environ.get("TMPDIR", "/tmp"), "ovg_bench_rccl_rank%d.log")
+
+
+def rccl_channels_observed(rank):
+    """Channel counts RCCL reported while it set up its communicators (NCCL_DEBUG=INFO lines "N coll channels, ... M p2p channels, K p2p
+    channels per peer", written to RCCL_LOG by this run): what sharding.available_cus() should have subtracted. None + reason when the
+    job configured NCCL_DEBUG itself or the lines are absent."""
+    import re
+    path = RCCL_LOG % rank
+    if os.environ.get("NCCL_DEBUG_FILE") != path:
+        return {"unavailable": "NCCL_DEBUG was set by the job: its own log has the channel lines"}
+    try:
+        text = open(path, errors="replace").read()
+    except OSError as e:
+        return {"unavailable": repr(e)[:120]}
+    out = {}
+    m = re.findall(r"(\d+) coll channels", text)
+    if m:
+        out["coll_channels"] = max(int(v) for v in m)
+    m = re.findall(r"(\d+) p2p channels(?:, (\d+) p2p channels per peer)?", text)
+    if m:
+        out["p2p_channels"] = max(int(a) for a, _ in m)
+        per = [int(b) for _, b in m if b]
+        if per:
+            out["p2p_channels_per_peer"] = max(per)
+    m = re.search(r"(?:RCCL|NCCL) version ([^\s]+)", text)
+    if m:
+        out["version"] = m.group(1)
+    return out or {"unavailable": "no channel lines in %s (%d bytes)" % (path, len(text))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,6 +267,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
+            # what RCCL actually sets up (channel counts) goes to a per-rank file that rank 0 parses into comm.rccl_channels_observed;
+            # a job that configured NCCL_DEBUG itself keeps its own settings (and the field reports that)
+            if "NCCL_DEBUG" not in os.environ:
+                os.environ["NCCL_DEBUG"] = "INFO"
+                os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,ENV")
+                os.environ["NCCL_DEBUG_FILE"] = RCCL_LOG % rank
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:                                     # host backend: ViewSharding stages its collectives through the host
             dist.init_process_group(args.backend, rank=rank, world_size=world)
@@ -369,6 +406,9 @@ def main():
         # what the launch plans of the global attention were told about the chip they share with RCCL (sharding.available_cus):
         # backend, rccl_channels / NCCL_MAX_NCHANNELS, attention_plan_cus of device_cus
         rep.update(shard.comm_report(torch.cuda.get_device_properties(dev).multi_processor_count))
+        rep["rccl_channels_observed"] = rccl_channels_observed(rank) if args.backend == "nccl" else None
+        if result.get("preflight", {}).get("attention_cus_table") is not None:
+            rep["attention_cus_table"] = result["preflight"]["attention_cus_table"]
         return rep
 
     S = args.views or 64
@@ -383,6 +423,13 @@ def main():
         torch.cuda.synchronize()
         pre["tolerance"] = 5e-2
         pre["agree"] = pre.get("max_rel_heads_vs_allgather", 0.0) <= pre["tolerance"]
+        # first-run insurance (round-5 review item 7): this rank's global-attention launch planned for 256 / 240 / 224 / 192 CUs, alone and
+        # with one layer's inbound exchange in flight -- does the reservation behind sharding.available_cus() pay on this node?
+        wd.stage("pre-flight: attention launch against the CU budgets")
+        try:
+            pre["attention_cus_table"] = shard.attention_cus_probe(agg, S, dev, [256, 240, 224, 192])
+        except RuntimeError as e:                  # host-side failure only; a hung collective is the watchdog's business
+            pre["attention_cus_table"] = {"error": repr(e)[:200]}
         result["preflight"] = pre
         if not pre["agree"] and args.shard_mode != "allgather":
             shard.mode = "allgather"

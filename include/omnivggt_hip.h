@@ -50,8 +50,11 @@ extern "C" {
  * 9: split-KV partials are f32 (ovg_attn_plan_out.part_bytes doubles) and a launch may split only the rows beyond its last full round
  *    along the keys (key-split tail, reported through main_rows / tail_q_tile); OVG_TILE_256P / OVG_TILE_DMA_M name the round-5 lab GEMM
  *    forms (OVG_E_UNSUPPORTED unless the library was built with -DOVG_LAB_GEMM)
- * 10: ovg_dpt_tail -- the output stage of the DPT head (upsample + position embedding + conv3x3 + ReLU + conv1x1 + activation) as one launch */
-#define OVG_ABI_VERSION 10
+ * 10: ovg_dpt_tail -- the output stage of the DPT head (upsample + position embedding + conv3x3 + ReLU + conv1x1 + activation) as one launch
+ * 11: the lab GEMM selectors of ABI 9 (OVG_TILE_256P / OVG_TILE_DMA_M) are removed (OVG_E_ARG); the key-split tail of ABI 9 now also follows
+ *     the 512-row attention launches (ovg_attn_plan_out: q_tile == tail_q_tile == 512, splits = key ranges of the tail rows, partials sized
+ *     for the tail rows) when the caller passes a split workspace */
+#define OVG_ABI_VERSION 11
 
 enum { OVG_BF16 = 0, OVG_F16 = 1, OVG_F32 = 2,
        /* split-f16 ("f32x", the <= 1e-4 mode with throughput): a value x is stored as hi = f16(x) (saturated at +-65504) in the tensor the
@@ -110,17 +113,13 @@ int ovg_layernorm(const ovg_layernorm_params*, void* stream);
  *                   (patch_embed.py:75-77 + vision_transformer.py:220-224)
  * ------------------------------------------------------------------ */
 enum { OVG_EPI_STORE = 0, OVG_EPI_GELU = 1, OVG_EPI_RES = 2, OVG_EPI_PATCH = 3 };
-/* workgroup tile of the GEMM kernels: 128 x 128 (4 waves, register-staged, up to 3 workgroups per CU) or 256 x 256 (8 waves,
- * LDS-DMA ring with ping-pong wave groups, 1 workgroup per CU, 16-bit dtypes); AUTO picks by shape (ovg_gemm.hip: choose_256) */
+/* workgroup tile of the GEMM kernels: 128 x 128 (4 waves, register-staged, up to 3 workgroups per CU) or 256 x 256 (8 waves, 4-slot LDS-DMA
+ * ring, software-pipelined "free-running" main loop with one barrier per k-stage, 1 workgroup per CU, 16-bit dtypes, N % 256 == 0);
+ * AUTO picks by shape (ovg_gemm.hip: choose_256). ABI 11: the round-5 lab selectors (4 = persistent 256 x 256, 8 = DMA-in-M flag) are gone --
+ * any other value is OVG_E_ARG. */
 enum { OVG_TILE_AUTO = 0, OVG_TILE_128 = 1, OVG_TILE_256 = 2,
-       /* persistent 256 x 256 (ABI 9): one workgroup per CU walks a balanced, row-granular share of the tiles, k-stage ring kept full across
-        * tiles, chunked epilogues (ovg_gemm256p.h); plain 16-bit dtypes, N % 256 == 0, K % 128 == 0 (OVG_F16X2 runs OVG_TILE_256 instead) */
-       OVG_TILE_256P = 4,
-       /* flag on OVG_TILE_256 / AUTO-resolved 256 x 256 launches: the k-stage DMA requests are issued between the MFMAs of the M sections
-        * instead of in the L sections (ovg_gemm256.h: DMA_M) */
-       OVG_TILE_DMA_M = 8, OVG_TILE_256M = 10,
        /* A/B flag, OR-ed onto any of the three: the same kernels with the r02 epilogue forms (erf_as GELU; per-lane 8- / 16-byte stores in
-        * the accumulator layout instead of whole lines staged through the idle LDS -- ovg_gemm.hip) */
+        * the accumulator layout instead of whole lines staged through the idle LDS -- ovg_gemm.hip); -DOVG_AB_VARIANTS builds only */
        OVG_TILE_R02_EPILOGUE = 16, OVG_TILE_128X = 17, OVG_TILE_256X = 18 };
 typedef struct {
   const void* x; int64_t ldx;

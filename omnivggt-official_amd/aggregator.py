@@ -250,7 +250,7 @@ class ZeroAggregator(nn.Module):
         self.attn_variant = 0       # ovg_attn_params.variant of every attention call (0 = library default); read per call
         self.gemm_tile = 0          # OVG_TILE_* forced on the block GEMMs (tests); 0 = shape heuristic
         self.attn_kv_splits = 0     # ovg_attn_params.kv_splits: 0 = library decides per launch, 1 = never split
-        self.attn_cus = 0           # ovg_attn_params.cus: CUs the attention launch plans may count on (0 = the whole device; ViewSharding sets it)
+        self.attn_cus = 0           # ovg_attn_params.cus of the BlockRunner launches (0 = the whole device). The sharded run leaves it at 0: frame / DINOv2 attention never overlaps an exchange; the global-attention launches that DO take their budget from sharding.HipExecutor.cus
         self.max_workspaces = 4     # scratch shapes kept alive (frame + global of the two most recent geometries)
         self.shard = None           # set by sharding.ViewSharding for the multi-GPU path
         self.fallback_counter = None    # enable_fallback_counter(): device int32 the attention launches count their re-run workgroups into

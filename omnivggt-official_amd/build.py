@@ -24,13 +24,19 @@ EXTRA_FLAGS = {"ovg_attn.hip": ["-fno-honor-nans"]}
 PINNED_ATTENTION_KERNELS = {"IDF16bLi4ELi8ELi0ELi2ELb0ELi5ELb0E": 4, "IDF16bLi4ELi4ELi0ELi2ELb0ELi3ELb0E": 4, "IDF16bLi2ELi4ELi0ELi2ELb0ELi3ELb0E": 2}
 
 
+# everything a pinned hot loop may contain besides scalar (s_*) instructions
+PINNED_LOOP_MNEMONICS = {"v_mfma_f32_16x16x32_bf16", "v_exp_f32", "v_cvt_pk_bf16_f32", "ds_read_b128",
+                         "v_add_u32_e32", "v_or_b32_e32", "v_lshl_or_b32", "v_lshl_add_u32", "v_add_lshl_u32", "v_lshlrev_b32_e32", "v_and_b32_e32"}
+
+
 def check_pinned_attention_loops(asm_text):
     """The order-pinned attention body (csrc/ovg_attn16_body_q*.inc: one `asm volatile` per MFMA / exp / convert / fragment read) is only
     correct while hipcc allocates registers AROUND those statements without materialising copies: it inserts no hazard wait states for
     inline asm, so a v_mov that builds a P fragment in front of the consuming asm MFMA, or a spilled accumulator, yields finite, plausible,
     WRONG attention output that the kernel's own post-pass check (row sums, non-finite values) need not catch (round-4 advisor finding).
     So the build itself disassembles what it just compiled and refuses to produce a library unless the hot loop of every shipped speculative
-    kernel holds exactly one tile's instructions and no v_mov / v_accvgpr / v_swap / scratch instruction. Returns the per-kernel counts."""
+    kernel holds exactly one tile's instructions and nothing outside PINNED_LOOP_MNEMONICS (+ scalar instructions). Returns the per-kernel counts.
+    build() reacts to a failure by recompiling ovg_attn.hip with the compiler-scheduled tile body (-DOVG_ATTN_PIPE_LOOP=0: slower, always correct)."""
     import re
     kernels, name, body = {}, None, []
     for line in asm_text.splitlines():
@@ -62,10 +68,14 @@ def check_pinned_attention_loops(asm_text):
         hot = pinned[0]
         if hot.count("v_cvt_pk_bf16_f32") != 8 * qb or hot.count("ds_read_b128") != 16:
             raise RuntimeError("pinned-attention check: %s hot loop holds %d converts / %d fragment reads" % (pat, hot.count("v_cvt_pk_bf16_f32"), hot.count("ds_read_b128")))
-        bad = [i for i in hot if i.startswith(("v_mov", "v_accvgpr", "scratch_", "v_swap", "v_pk_mov"))]
+        # WHITELIST (round-5 advisor: a blacklist of v_mov / v_accvgpr / ... would let any other compiler-inserted VALU write into an MFMA
+        # source pass): besides scalar instructions the hot loop may hold exactly the tile's own matrix / exp / convert instructions, the
+        # fragment reads, and the integer address arithmetic of the ring (which writes LDS addresses, never an MFMA operand)
+        bad = [i for i in hot if not (i.startswith("s_") or i in PINNED_LOOP_MNEMONICS)]
         if bad:
-            raise RuntimeError("pinned-attention check: hipcc materialised register copies / spills inside the pinned hot loop of %s: %r -- the "
-                               "bf16 attention results of this build are NOT trustworthy; rebuild with -DOVG_ATTN_PIPE_LOOP=0 or fix the body" % (pat, bad))
+            raise RuntimeError("pinned-attention check: hipcc put instructions outside the pinned tile's own set (register copies / spills / "
+                               "re-materialised operands) inside the hot loop of %s: %r -- the bf16 attention results of such a build are NOT "
+                               "trustworthy" % (pat, sorted(set(bad))))
         report[pat] = {"instructions": len(hot), "mfma": 18 * qb}
     return report
 
@@ -123,9 +133,9 @@ def build(force=False, verbose=True):
             os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
             objdir = tempfile.mkdtemp(prefix="obj.", dir=os.path.join(HERE, "build"))
 
-            def cc(src):
+            def cc(src, extra=()):
                 obj = os.path.join(objdir, src.replace(".hip", ".o"))
-                cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+                cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), *extra, "-c", os.path.join(CSRC, src), "-o", obj]
                 if src == "ovg_attn.hip":
                     cmd.insert(1, "-save-temps=obj")          # keeps the gfx950 assembly of THIS compile next to the object: checked below
                 r = subprocess.run(cmd, capture_output=True, text=True)
@@ -133,11 +143,19 @@ def build(force=False, verbose=True):
                     raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
                 if verbose and r.stderr.strip():
                     sys.stderr.write(r.stderr)
-                if src == "ovg_attn.hip":
+                if src == "ovg_attn.hip" and not extra:
                     asm = [f for f in os.listdir(objdir) if f.startswith("ovg_attn") and f.endswith(".s") and "gfx950" in f]
                     if len(asm) != 1:
                         raise RuntimeError("pinned-attention check: expected one gfx950 assembly file of ovg_attn.hip, found %r" % asm)
-                    check_pinned_attention_loops(open(os.path.join(objdir, asm[0])).read())
+                    try:
+                        check_pinned_attention_loops(open(os.path.join(objdir, asm[0])).read())
+                    except RuntimeError as e:
+                        # a hipcc that schedules the pinned body differently must not leave the user without a library (round-5 advisor):
+                        # the compiler-scheduled body is the same arithmetic without hand-placed instructions -- nothing for the guard to
+                        # check -- at a few percent of attention throughput
+                        sys.stderr.write("WARNING: %s\nWARNING: rebuilding ovg_attn.hip with -DOVG_ATTN_PIPE_LOOP=0 (compiler-scheduled attention "
+                                         "tile body: correct, slower); fix csrc/ovg_attn16_body_q*.inc for this compiler to get the pinned loop back\n" % e)
+                        return cc(src, extra=("-DOVG_ATTN_PIPE_LOOP=0",))
                 return obj
 
             try:

@@ -303,6 +303,7 @@ Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
   if (v == 71) v = 57;            // A/B tool: the 512-row kernel with its tail split (dispatch16)
   if (v == 72) v = 50;            // A/B tool: the 256-row kernel with a tail split (dispatch16)
   if (v == 73) v = 50;            // A/B tool: the 256-row kernel with a key-split tail (dispatch16)
+  if (v == 74) { if (kvs > 1) { forced_tail = kvs; kvs = 0; } v = 57; }   // A/B tool: the 512-row kernel with a key-split tail (+ kv_splits s = exactly s ranges)
   const int cus = (p.cus > 0 && p.cus < cu_count_attn()) ? p.cus : cu_count_attn();   // ovg_attn_params.cus: what RCCL leaves us in the sharded run
   const int64_t units512 = p.BH * ((p.nq + 511) / 512);
   // 512-row tiles (8 waves, one workgroup per CU, barrier every 2 tiles) from ~2.5 rounds of them on: 16 views +5.9 %, 64 views +3 %
@@ -394,7 +395,8 @@ Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
     const int64_t rows_a = full * tslots / p.BH * pl.bq;
     // s key ranges per tail unit so that the tail launch stays within ONE round of slots (8 views: 176 units -> 2 ranges = 352 pieces; 3 ranges =
     // 528 pieces on 512 slots measured 5 % SLOWER than the unsplit launch, profiles/r05_attention_keytail_ab.txt)
-    int s = forced_tail ? forced_tail : (rest > 0 ? (int)(tslots / rest) : 1);
+    const int64_t tail_units_256 = rows_a < p.nq ? p.BH * ((p.nq - rows_a + pl.bq - 1) / pl.bq) : 0;   // >= rest: rows_a rounds down per entry when BH does not divide a round (round-5 advisor)
+    int s = forced_tail ? forced_tail : (tail_units_256 > 0 ? (int)(tslots / tail_units_256) : 1);
     s = s > OVG_MAX_SEG ? OVG_MAX_SEG : s;
     while (s > 2 && (pl.total_tiles + s - 1) / s < 16) --s;
     // measured (profiles/r05_attention_keytail_ab.txt, r05_attention_keytail_factors_ab.txt; unsplit -> key-split tail, ms): 13 views (2.19 rounds)
@@ -402,6 +404,43 @@ Plan16 plan16(const ovg_attn_params& p, bool bf16, bool have_ws) {
     // a last round that is a third full or more already runs fast on its lone workgroups. So: a tail of at most a quarter of a round.
     const bool want = p.variant == 73 ? (full >= 1 && rest > 0) : (full >= 1 && full <= 3 && frac >= 0.05 && frac <= 0.25);
     if (want && s >= 2 && rows_a > 0 && rows_a < p.nq && (pl.total_tiles + s - 1) / s >= 16) { pl.main_rows = rows_a; pl.tail_splits = s; }
+  }
+  // ---- key-split tail of the 512-row kernel (round 6; workspace given) ----
+  // The 128-row tail launch above walks ALL keys of a head with 32 rows per wave: whatever its size it costs 0.6-0.9 of a full 512-row round
+  // (64 views: 2.0 ms for 0.73 of a round's rows, 0.757 GB of fabric reads for 6.8 % of the work; 48 views: 0.65 of a round for 0.06 of one), and
+  // it re-reads K / V^T once per 128 rows. Instead the rows beyond the last full round stay 512-row tiles (64 rows per wave, a quarter of the K / V^T
+  // re-reads) and are cut along the KEYS into s ranges, s chosen so that tail units x s fills whole rounds of the chip (64 views: 192 units x 4 =
+  // 768 = 3 rounds of quarter-length units = 0.75 of a round for 0.73 of a round's rows), + the exact log-sum-exp merge on those rows only.
+  // Cost model in units of one full 512-row round (fitted to profiles/r06_attention_tail512_ab.txt, 16 / 64 views x s = 2..8): the 128-row tail
+  // max(0.6, 0.9 x its share of a round of 3 x CUs slots) (r02 / r05 / r06 measurements at 32 / 48 / 64 views: 0.58 / 0.65 / 0.90); a key split
+  // (full rounds + sqrt(fraction of the last one)) / s -- a partly filled round of lone workgroups runs faster than a full one -- x (1 + 6 key
+  // tiles of fixed cost per unit: Q load, ring fill, f32 partial store) + 0.03 for the merge launch, with a small preference for MORE ranges
+  // while a range still holds >= 128 key tiles (64 views: s = 8 measured 23.50 ms against 23.59 at s = 4 with identical round counts: finer units
+  // fill the ragged end of the launch); no tail launch at all: 1. Measured, old 128-row tail -> this rule: 16 / 24 / 32 / 48 / 64 views
+  // 1.597 -> 1.557 / 3.632 -> 3.433 / 6.152 -> 5.985 / 13.825 -> 13.447 / 23.98 -> 23.50 ms (+2.6 / +5.8 / +2.8 / +2.8 / +2.0 %).
+  if (pl.splits == 1 && v == 57 && have_ws && kvs == 0 && pl.tail_splits == 0 && (p.variant == 0 || p.variant == 74)) {
+    const int64_t full = units / cus;
+    const int64_t rows_a = full * cus / p.BH * pl.bq;
+    const int64_t rest_rows = p.nq - rows_a;
+    if (full >= 2 && rows_a > 0 && rest_rows > 0) {
+      const int64_t tail_units = p.BH * ((rest_rows + pl.bq - 1) / pl.bq);          // from the ACTUAL tail rows (rows_a rounds down when BH does not divide a round)
+      const int64_t t128 = p.BH * ((rest_rows + 127) / 128);
+      double base = 1.0;                                     // what the launch pays for these rows today
+      if (pl.tail_bq) { const double c = 0.9 * (double)t128 / (3.0 * cus); base = c < 0.6 ? 0.6 : c; }
+      double best = 1e30;
+      int best_s = 0;
+      for (int s = 2; s <= OVG_MAX_SEG; ++s) {
+        const int per = (pl.total_tiles + s - 1) / s;
+        if (per < 32) break;
+        if (forced_tail && s != forced_tail) continue;
+        const double rounds = (double)(tail_units * s) / cus, whole = floor(rounds);
+        double c = (whole + sqrt(rounds - whole)) / s * (1.0 + 6.0 / per) + 0.03;
+        if (per >= 128) c *= 1.0 - 0.006 * s;
+        if (c < best) { best = c; best_s = s; }
+      }
+      if (!forced_tail && best >= base * 0.97) best_s = 0;   // a split must be worth >= 3 % of a round
+      if (best_s) { pl.main_rows = rows_a; pl.tail_bq = 0; pl.tail_splits = best_s; }
+    }
   }
   return pl;
 }
@@ -456,12 +495,15 @@ int dispatch16(const ovg_attn_params& p, hipStream_t st) {
   }
   if (pl.tail_splits > 1) {                         // key-split tail (plan16): full rounds unsplit, then the remaining rows cut along the keys + merge
     const bool lazy = pl.variant == 52;             // f16 default: lazy-rescale body
-    int rc = lazy ? launch_attn16<T, 4, 4, 1, 2, false, 3>(p, pl, st, 0, pl.main_rows) : launch_attn16<T, 4, 4, 0, 2, false, 3>(p, pl, st, 0, pl.main_rows);
+    const bool big = pl.variant == 57;              // 512-row tiles (round 6)
+    int rc = big ? launch_attn16<T, 4, 8, 0, 2, false, 5>(p, pl, st, 0, pl.main_rows)
+                 : (lazy ? launch_attn16<T, 4, 4, 1, 2, false, 3>(p, pl, st, 0, pl.main_rows) : launch_attn16<T, 4, 4, 0, 2, false, 3>(p, pl, st, 0, pl.main_rows));
     if (rc != OVG_OK) return rc;
     Plan16 tp = pl;
     tp.per_split = (pl.total_tiles + pl.tail_splits - 1) / pl.tail_splits;
     tp.splits = (pl.total_tiles + tp.per_split - 1) / tp.per_split;
-    return lazy ? launch_attn16<T, 4, 4, 1, 2, false, 3>(p, tp, st, pl.main_rows, p.nq) : launch_attn16<T, 4, 4, 0, 2, false, 3>(p, tp, st, pl.main_rows, p.nq);
+    return big ? launch_attn16<T, 4, 8, 0, 2, false, 5>(p, tp, st, pl.main_rows, p.nq)
+               : (lazy ? launch_attn16<T, 4, 4, 1, 2, false, 3>(p, tp, st, pl.main_rows, p.nq) : launch_attn16<T, 4, 4, 0, 2, false, 3>(p, tp, st, pl.main_rows, p.nq));
   }
   if (pl.tail_bq) {                                 // tail split (plan16): full rounds of big tiles, then the remaining rows as 128-row tiles
     const int rc = pl.variant == 57 ? launch_attn16<T, 4, 8, 0, 2, false, 5>(p, pl, st, 0, pl.main_rows)

@@ -167,6 +167,12 @@ OVG_DEV void lds_dma16(const void* gsrc, uint32_t lds_dst) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_dst), "v"(gsrc) : "memory");
 }
 
+// The same with the address split into a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset: a k-stage then advances by ONE
+// scalar add on the base instead of a 64-bit vector add per request, and a request's address costs one VGPR instead of two.
+OVG_DEV void lds_dma16_s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+}
+
 // Raw buffer descriptor (4 SGPRs): base, stride 0, num_records = bytes, untyped dword format. Lanes whose offset (VGPR offset + immediate;
 // the SGPR offset is NOT range-checked) reaches num_records read as zero and fetch nothing.
 typedef int32_t i32x4 __attribute__((ext_vector_type(4)));

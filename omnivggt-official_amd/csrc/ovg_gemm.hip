@@ -808,8 +808,8 @@ __global__ __launch_bounds__(256, 3) void qkv_kernel(ovg_qkv_params p, int nt_be
 
 #include "ovg_gemm256.h"
 
-// 256 x 256 ping-pong variants (16-bit modes): same epilogues on acc[4][8]
-template <typename T, int EPI, bool OUT_F32, int XP = 0, bool X3 = false, bool ML = false>   // ML: main loop with the DMA requests inside the M sections (ovg_gemm256.h)
+// 256 x 256 variants (16-bit modes): same epilogues on acc[4][8]
+template <typename T, int EPI, bool OUT_F32, int XP = 0, bool X3 = false>
 __global__ __launch_bounds__(512) void linear256_kernel(ovg_linear_params p, int ntiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds256[];
   const int M = (int)p.M, N = (int)p.N, K = (int)p.K;
@@ -819,8 +819,8 @@ __global__ __launch_bounds__(512) void linear256_kernel(ovg_linear_params p, int
   tile_coords(xcd_remap(blockIdx.x, gridDim.x), (M + g256::BM2 - 1) / g256::BM2, ntiles_n, tm, tn);
   const int m0 = tm * g256::BM2, n0 = tn * g256::BN2;
   f32x4 acc[4][8];
-  g256::mainloop<T, false, X3, ML>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds256, acc,
-                               static_cast<const T*>(p.x_lo), static_cast<const T*>(p.w_lo));
+  g256::mainloop<T, false, X3>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, M, N, K, m0, n0, lds256, acc,
+                                static_cast<const T*>(p.x_lo), static_cast<const T*>(p.w_lo));
   tl_mark(2);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // the ring is idle: mainloop() returns behind its last barrier, every DMA waited for; wave w owns 16 KB of it
@@ -828,7 +828,7 @@ __global__ __launch_bounds__(512) void linear256_kernel(ovg_linear_params p, int
   tl_mark(3);
 }
 
-template <typename T, bool X3 = false, bool ML = false>
+template <typename T, bool X3 = false>
 __global__ __launch_bounds__(512) void qkv256_kernel(ovg_qkv_params p, int nt_begin, int nt_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds256[];   // ring (g256::LDS_BYTES) + RoPE table (ROPE_LDS_BYTES)
   constexpr int N = 3 * OVG_C, K = OVG_C;
@@ -841,15 +841,15 @@ __global__ __launch_bounds__(512) void qkv256_kernel(ovg_qkv_params p, int nt_be
   const int wave = threadIdx.x >> 6;
   f32x4 acc[4][8];
   if (n0 >= 2 * OVG_C) {                                   // V^T tile (workgroup-uniform): transposed accumulators
-    g256::mainloop<T, true, X3, ML>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds256, acc,
-                                static_cast<const T*>(p.x_lo), static_cast<const T*>(p.w_lo));
+    g256::mainloop<T, true, X3>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds256, acc,
+                                 static_cast<const T*>(p.x_lo), static_cast<const T*>(p.w_lo));
     tl_mark(2);
     v_epilogue<T, 8, X3>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64);
   } else {
     float* rope_tab = reinterpret_cast<float*>(lds256 + g256::LDS_BYTES);
     stage_rope_table(p, lds256 + g256::LDS_BYTES, 8);      // older than every stage DMA: retired by the loop's first counted wait, visible after its barriers
-    g256::mainloop<T, false, X3, ML>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds256, acc,
-                                 static_cast<const T*>(p.x_lo), static_cast<const T*>(p.w_lo));
+    g256::mainloop<T, false, X3>(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, M, N, K, m0, n0, lds256, acc,
+                                  static_cast<const T*>(p.x_lo), static_cast<const T*>(p.w_lo));
     // the OVG_TILE_R02_EPILOGUE flag keeps the r02 per-lane 8-byte stores (A/B); otherwise whole head rows through the idle ring
     unsigned char* img = (X3 || (p.tile & OVG_TILE_R02_EPILOGUE)) ? nullptr : lds256 + __builtin_amdgcn_readfirstlane(wave) * 16384;
     tl_mark(2);
@@ -857,102 +857,6 @@ __global__ __launch_bounds__(512) void qkv256_kernel(ovg_qkv_params p, int nt_be
   }
   tl_mark(3);
 }
-
-// Round-5 lab forms, compiled only with -DOVG_LAB_GEMM (tools/probes/build_alt.py lab=-DOVG_LAB_GEMM): the persistent kernels of
-// ovg_gemm256p.h (OVG_TILE_256P) and the DMA-in-M main loop (OVG_TILE_DMA_M). Both are parity-green (56 checks of gpu_selftest.py gemm256p /
-// gemm256m) and SLOWER than the shipped kernels (profiles/r05_gemm_persistent_v1_ab.txt, r05_gemm_dma_in_m_ab.txt); DESIGN 4.1 has the numbers
-// and what they say about where a tile's time goes. The product library answers OVG_E_UNSUPPORTED to both selectors.
-#ifdef OVG_LAB_GEMM
-#include "ovg_gemm256p.h"
-
-// Persistent forms (ovg_gemm256p.h): one workgroup per CU, balanced row-granular pieces, k-stage ring kept full across pieces,
-// chunked epilogues. fcost = fixed cost of a piece in units of 32 rows (host: persistent_fcost).
-template <typename T, int EPI, bool OUT_F32>
-__global__ __launch_bounds__(512) void linear256p_kernel(ovg_linear_params p, int ntiles_gm, int fcost) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds256[];
-  const int M = (int)p.M, N = (int)p.N, K = (int)p.K;
-  g256p::Walker wk;
-  wk.init(xcd_remap(blockIdx.x, gridDim.x), gridDim.x, M, N, fcost, ntiles_gm);
-  g256p::Piece cur, nxt;
-  if (!wk.next(cur)) return;                               // workgroup-uniform
-  tl_begin_persistent();
-  g256p::Ctx<T> cx;
-  cx.init(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), p.ldw, N, K, lds256);
-  unsigned char* img = lds256 + g256p::EPI_SLOT * g256::STAGE_B + cx.wave * g256p::EPI_WAVE_BYTES;
-  f32x4 acc[4][8];
-  bool first = true;
-  for (;;) {
-    const bool have_next = wk.next(nxt);
-    if (!have_next) nxt = cur;
-    const unsigned long long tl0 = tl_now();
-    if (cur.mtc == 8) g256p::run_piece<T, false, false>(cx, cur, first, have_next, nxt, acc);
-    else g256p::run_piece<T, false, true>(cx, cur, first, have_next, nxt, acc);
-    const unsigned long long tl1 = tl_now();
-    const int m_w0 = cur.m0 + cx.wm * 16 * cur.mtc, n_w0 = cur.n0 + cx.wn * 64;
-    const int g_end = m_w0 + 16 * cur.mtc;
-    const int row_lim = g_end < cur.row_end ? g_end : cur.row_end;
-    const ovg_linear_params pe = g256p::reload_params<ovg_linear_params>();     // the epilogue's view of p (see reload_params)
-    bool staged = false;
-    if constexpr ((EPI == OVG_EPI_STORE || EPI == OVG_EPI_GELU) && !OUT_F32) {
-      if (((pe.ldy * (int64_t)sizeof(T)) & 15) == 0) { g256p::epilogue16<T, EPI>(pe, acc, m_w0, n_w0, row_lim, cur.mtc, img); staged = true; }
-    }
-    if constexpr (EPI == OVG_EPI_RES) {
-      g256p::epilogue_res(pe, acc, m_w0, n_w0, row_lim, cur.mtc, img);   // injection rows included (the host sends inj_period < 128 elsewhere)
-      staged = true;
-    } else {
-      if (!staged) linear_epilogue<T, EPI, OUT_F32, 8>(pe, acc, m_w0, n_w0, row_lim);
-    }
-    tl_piece(tl0, tl1, tl_now());
-    tl_mark(3);
-    if (!have_next) break;
-    cur = nxt;
-    first = false;
-  }
-}
-
-// VT: the launch covers V^T tiles only (transposed accumulators, v_epilogue); !VT: q / k tiles only. Two launches per projection instead
-// of one kernel that holds both main-loop forms and both epilogues: as one function hipcc spilled 300-800 VGPRs, the accumulators among them.
-template <typename T, bool VT>
-__global__ __launch_bounds__(512) void qkv256p_kernel(ovg_qkv_params p, int nt_begin, int nt_count_gm, int fcost) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds256[];   // ring (g256::LDS_BYTES) + RoPE table (ROPE_LDS_BYTES)
-  constexpr int K = OVG_C;
-  const int M = (int)p.M;
-  const int ntc = nt_count_gm & 0xffff;
-  g256p::Walker wk;
-  wk.init(xcd_remap(blockIdx.x, gridDim.x), gridDim.x, M, ntc * g256::BN2, fcost, nt_count_gm);
-  g256p::Piece cur, nxt;
-  if (!wk.next(cur)) return;
-  tl_begin_persistent();
-  cur.n0 += nt_begin * g256::BN2;
-  g256p::Ctx<T> cx;
-  cx.init(static_cast<const T*>(p.x), p.ldx, static_cast<const T*>(p.w), (int64_t)K, 3 * OVG_C, K, lds256);
-  float* rope_tab = reinterpret_cast<float*>(lds256 + g256::LDS_BYTES);
-  if constexpr (!VT) stage_rope_table(p, lds256 + g256::LDS_BYTES, 8);   // older than every stage DMA: retired by the first piece's counted wait, visible after its barriers
-  unsigned char* img = lds256 + g256p::EPI_SLOT * g256::STAGE_B + cx.wave * g256p::EPI_WAVE_BYTES;
-  f32x4 acc[4][8];
-  bool first = true;
-  for (;;) {
-    const bool have_next = wk.next(nxt);
-    if (have_next) nxt.n0 += nt_begin * g256::BN2; else nxt = cur;
-    const unsigned long long tl0 = tl_now();
-    if (cur.mtc == 8) g256p::run_piece<T, VT, false>(cx, cur, first, have_next, nxt, acc);
-    else g256p::run_piece<T, VT, true>(cx, cur, first, have_next, nxt, acc);
-    const unsigned long long tl1 = tl_now();
-    const int m_w0 = cur.m0 + cx.wm * 16 * cur.mtc, n_w0 = cur.n0 + cx.wn * 64;
-    const int g_end = m_w0 + 16 * cur.mtc;
-    const int row_lim = g_end < cur.row_end ? g_end : cur.row_end;
-    const ovg_qkv_params pe = g256p::reload_params<ovg_qkv_params>();
-    if constexpr (VT) v_epilogue<T, 8>(pe, acc, m_w0, n_w0, row_lim);
-    else g256p::qk_epilogue_chunked<T>(pe, acc, m_w0, n_w0, row_lim, cur.mtc, rope_tab, rope_tab + 128 * 16, img);
-    tl_piece(tl0, tl1, tl_now());
-    tl_mark(3);
-    if (!have_next) break;
-    cur = nxt;
-    first = false;
-  }
-}
-
-#endif  // OVG_LAB_GEMM
 
 // Opt a kernel in to > 64 KB of dynamic LDS. The attribute is PER DEVICE, so it is set once per (kernel, device) -- a process
 // that drives a second GPU must not inherit the first one's "already done" (round-2 review: function-local statics did that).
@@ -1012,29 +916,18 @@ int launch_linear128(const ovg_linear_params& p, hipStream_t st) {
   }
   return launch_linear128_xp<T, 0>(p, st);
 }
-template <typename T, int EPI, bool OUT_F32, int XP = 0, bool ML = false>
+template <typename T, int EPI, bool OUT_F32, int XP = 0>
 int launch_linear256_one(const ovg_linear_params& p, hipStream_t st) {
-  const int ok = allow_big_lds(linear256_kernel<T, EPI, OUT_F32, XP, false, ML>);
+  const int ok = allow_big_lds(linear256_kernel<T, EPI, OUT_F32, XP>);
   if (ok != OVG_OK) return ok;
   const int mt = (int)((p.M + g256::BM2 - 1) / g256::BM2), nt = (int)(p.N / g256::BN2);
   const int ntg = nt | (TILE_GROUP256 << 16);
-  OVG_LAUNCH((linear256_kernel<T, EPI, OUT_F32, XP, false, ML>), dim3(mt * nt), dim3(512), g256::LDS_BYTES, st, p, ntg);
+  OVG_LAUNCH((linear256_kernel<T, EPI, OUT_F32, XP>), dim3(mt * nt), dim3(512), g256::LDS_BYTES, st, p, ntg);
   OVG_CHECK_LAUNCH();
   return OVG_OK;
 }
 template <typename T>
 int launch_linear256(const ovg_linear_params& p, hipStream_t st, bool xp) {
-#ifdef OVG_LAB_GEMM
-  if ((p.tile & OVG_TILE_DMA_M) && !xp) {
-    switch (p.epilogue) {
-      case OVG_EPI_STORE: return p.out_f32 ? launch_linear256_one<T, OVG_EPI_STORE, true, 0, true>(p, st) : launch_linear256_one<T, OVG_EPI_STORE, false, 0, true>(p, st);
-      case OVG_EPI_GELU: return launch_linear256_one<T, OVG_EPI_GELU, false, 0, true>(p, st);
-      case OVG_EPI_RES: return launch_linear256_one<T, OVG_EPI_RES, true, 0, true>(p, st);
-      case OVG_EPI_PATCH: return launch_linear256_one<T, OVG_EPI_PATCH, true, 0, true>(p, st);
-      default: return OVG_E_ARG;
-    }
-  }
-#endif
 #ifdef OVG_AB_VARIANTS
   if (xp) {                                          // A/B flag: the r02 epilogue forms
     switch (p.epilogue) {
@@ -1056,71 +949,6 @@ int launch_linear256(const ovg_linear_params& p, hipStream_t st, bool xp) {
     default: return OVG_E_ARG;
   }
 }
-#ifdef OVG_LAB_GEMM
-// ---- persistent kernels: launch geometry ----
-// One workgroup per CU (the 128 KB ring admits exactly one). Cached per device like allow_big_lds.
-int device_cus() {
-  static std::mutex mu;
-  static std::vector<std::pair<int, int>> memo;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return -1;
-  std::lock_guard<std::mutex> lock(mu);
-  for (const auto& d : memo)
-    if (d.first == dev) return d.second;
-  int n = 0;
-  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return -1;
-  memo.emplace_back(dev, n);
-  return n;
-}
-// Fixed cost of a piece (time outside its main loop: epilogue + hand-over) in units of 32 rows of main loop, i.e. of ~2.75 us x K / 1024
-// (profiles/r05_gemm_timeline.txt): what the balanced split charges for cutting a tile in two. kind: OVG_EPI_* or 4 = QKV.
-int persistent_fcost(int kind, int64_t K) {
-  const float fixed_us = kind == OVG_EPI_RES ? 10.0f : (kind == OVG_EPI_PATCH ? 8.0f : (kind == OVG_EPI_STORE ? 5.0f : 6.5f));
-  const float unit_us = 2.75f * (float)K / 1024.0f;
-  int f = (int)(fixed_us / unit_us + 0.5f);
-  return f < 1 ? 1 : (f > 8 ? 8 : f);
-}
-int persistent_grid(int64_t M, int64_t N, int fcost, int cus) {
-  // never more workgroups than units of work: a workgroup's slice must be able to hold at least one 32-row unit
-  const int64_t T = ((M + g256::BM2 - 1) / g256::BM2) * (N / g256::BN2);
-  const int64_t cap = T * g256p::UPT;
-  return (int)(cap < cus ? cap : cus);
-}
-bool persistent_legal(bool sixteen_bit, int64_t N, int64_t K) { return sixteen_bit && N % g256::BN2 == 0 && K % 128 == 0 && K >= 128; }
-// the chunked epilogues address their output (and residual) with 32-bit byte offsets from the tensor base, and find injection rows with
-// scalar arithmetic that assumes at most one per 128-row wave block
-bool persistent_legal_out(const ovg_linear_params& p) {
-  const int64_t osz = (p.out_f32 || p.epilogue == OVG_EPI_RES || p.epilogue == OVG_EPI_PATCH) ? 4 : 2;
-  const int64_t rows = p.epilogue == OVG_EPI_PATCH ? (p.M / (p.p0 > 0 ? p.p0 : 1) + 1) * p.p1 + p.row_off : p.M;
-  if (rows * p.ldy * osz >= (int64_t)1 << 32) return false;
-  if (p.epilogue == OVG_EPI_RES && (p.M * p.ldres * 4 >= (int64_t)1 << 32 || (p.inject && p.inj_period < 128))) return false;
-  return true;
-}
-
-template <typename T, int EPI, bool OUT_F32>
-int launch_linear256p_one(const ovg_linear_params& p, hipStream_t st) {
-  const int ok = allow_big_lds(linear256p_kernel<T, EPI, OUT_F32>);
-  if (ok != OVG_OK) return ok;
-  const int cus = device_cus();
-  if (cus <= 0) return OVG_E_LAUNCH;
-  const int nt = (int)(p.N / g256::BN2), fc = persistent_fcost(p.epilogue, p.K);
-  OVG_LAUNCH((linear256p_kernel<T, EPI, OUT_F32>), dim3(persistent_grid(p.M, p.N, fc, cus)), dim3(512), g256::LDS_BYTES, st, p, nt | (TILE_GROUP256 << 16), fc);
-  OVG_CHECK_LAUNCH();
-  return OVG_OK;
-}
-template <typename T>
-int launch_linear256p(const ovg_linear_params& p, hipStream_t st) {
-  switch (p.epilogue) {
-    case OVG_EPI_STORE: return p.out_f32 ? launch_linear256p_one<T, OVG_EPI_STORE, true>(p, st) : launch_linear256p_one<T, OVG_EPI_STORE, false>(p, st);
-    case OVG_EPI_GELU: return launch_linear256p_one<T, OVG_EPI_GELU, false>(p, st);
-    case OVG_EPI_RES: return launch_linear256p_one<T, OVG_EPI_RES, true>(p, st);
-    case OVG_EPI_PATCH: return launch_linear256p_one<T, OVG_EPI_PATCH, true>(p, st);
-    default: return OVG_E_ARG;
-  }
-}
-
-#endif  // OVG_LAB_GEMM
-
 // Tile choice for the 16-bit modes. Isolated A/B (tests/bench_kernels.py gemm, profiles/r02_gemm_epilogue_mlp.txt): with the
 // r02 epilogues the 256 x 256 ping-pong loop wins on QKV / fc1 / fc2 at both bench sizes (M = 10 992: +7 / +13 / +19 %,
 // M = 87 936: +28 / +5 / +17 %); the proj GEMM (K = 1024, f32 residual epilogue) is a tie at M = 87 936 and better on
@@ -1133,19 +961,12 @@ int launch_linear256p(const ovg_linear_params& p, hipStream_t st) {
 // where they are worth +1 % (16 views) ... +2 % (64 views) on the forward. Re-checked in r03 with the staged-store epilogues
 // (profiles/r03_gemm_mlp256_insitu.txt): fc1 / fc2 alone on 256 x 256 below the threshold -- isolated +8 / +17 % at M = 10 992 -- still
 // LOSES in situ (4 / 8 / 12 views: -6.5 / -4 / -2.5 %; the global attention behind them 0.445 -> 0.482 ms): the threshold stays.
-// Returns 2 = persistent 256^2 (ovg_gemm256p.h, lab builds), 1 = use 256^2, 0 = use 128^2, -1 = the caller forced a tile this shape / dtype cannot run,
-// -2 = the caller asked for a lab form this build does not contain.
+// Returns 1 = use 256^2, 0 = use 128^2, -1 = the caller forced a tile this shape / dtype cannot run.
 int choose_256(int tile_arg, bool sixteen_bit, int64_t M, int64_t N, int64_t K, bool light_epilogue_or_long_k) {
-  const int tile = tile_arg & ~(OVG_TILE_R02_EPILOGUE | OVG_TILE_DMA_M);      // the A/B flags do not take part in the tile choice
-  const bool legal = sixteen_bit && N % g256::BN2 == 0 && K % 32 == 0;
-#ifndef OVG_LAB_GEMM
-  if (tile == OVG_TILE_256P || (tile_arg & OVG_TILE_DMA_M)) return -2;          // lab forms: not in this build
-#endif
+  const int tile = tile_arg & ~OVG_TILE_R02_EPILOGUE;      // the A/B flag does not take part in the tile choice
+  const bool legal = sixteen_bit && N % g256::BN2 == 0 && K % 64 == 0;
   if (tile == OVG_TILE_128) return 0;
   if (tile == OVG_TILE_256) return legal ? 1 : -1;
-#ifdef OVG_LAB_GEMM
-  if (tile == OVG_TILE_256P) return persistent_legal(sixteen_bit, N, K) ? 2 : -1;
-#endif
   if (tile != OVG_TILE_AUTO) return -1;
   if (!legal || !light_epilogue_or_long_k || M < 20000) return 0;
   return 1;
@@ -1154,11 +975,8 @@ int choose_256(int tile_arg, bool sixteen_bit, int64_t M, int64_t N, int64_t K, 
 template <typename T>
 int launch_linear(const ovg_linear_params& p, hipStream_t st) {
   const int big = choose_256(p.tile, sizeof(T) == 2, p.M, p.N, p.K, p.epilogue != OVG_EPI_RES || p.K >= 2048);
-  if (big < 0) return big == -2 ? OVG_E_UNSUPPORTED : OVG_E_ARG;
+  if (big < 0) return OVG_E_ARG;
   if constexpr (sizeof(T) == 2) {
-#ifdef OVG_LAB_GEMM
-    if (big == 2) return persistent_legal_out(p) ? launch_linear256p<T>(p, st) : OVG_E_ARG;
-#endif
     if (big) return launch_linear256<T>(p, st, (p.tile & OVG_TILE_R02_EPILOGUE) != 0);
   }
   return launch_linear128<T>(p, st);
@@ -1182,8 +1000,7 @@ int launch_linear_x3_one(const ovg_linear_params& p, hipStream_t st, bool big) {
 }
 int launch_linear_x3(const ovg_linear_params& p, hipStream_t st) {
   int big = choose_256(p.tile, true, p.M, p.N, p.K, true);
-  if (big < 0) return big == -2 ? OVG_E_UNSUPPORTED : OVG_E_ARG;
-  if (big == 2) big = 1;                                   // the persistent form exists for the plain 16-bit modes only
+  if (big < 0) return OVG_E_ARG;
   switch (p.epilogue) {
     case OVG_EPI_STORE: return p.out_f32 ? launch_linear_x3_one<OVG_EPI_STORE, true>(p, st, big) : launch_linear_x3_one<OVG_EPI_STORE, false>(p, st, big);
     case OVG_EPI_GELU: return launch_linear_x3_one<OVG_EPI_GELU, false>(p, st, big);
@@ -1258,51 +1075,13 @@ extern "C" int ovg_qkv(const ovg_qkv_params* p, void* stream) {
   if (p->part < 0 || p->part > 2) return OVG_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int big = choose_256(p->tile, p->dtype != OVG_F32, p->M, (p->part == 0 ? 3 : (p->part == 1 ? 2 : 1)) * OVG_C, OVG_C, true);
-  if (big < 0) return big == -2 ? OVG_E_UNSUPPORTED : OVG_E_ARG;
-#ifdef OVG_LAB_GEMM
-  if (big == 2 && (p->dtype == OVG_BF16 || p->dtype == OVG_F16)) {
-    // two persistent launches: q / k tiles (part 0: 8 n-tiles from 0; part 1: k only; part 2: q only), then the V^T tiles (parts 0, 1)
-    const int q_t = OVG_C / g256::BN2;
-    const int cus = device_cus();
-    if (cus <= 0) return OVG_E_LAUNCH;
-    const int fc = persistent_fcost(4, OVG_C);
-    const int qk_b = p->part == 1 ? q_t : 0, qk_c = p->part == 0 ? 2 * q_t : q_t;
-    const dim3 grid_qk((unsigned)persistent_grid(p->M, (int64_t)qk_c * g256::BN2, fc, cus)), grid_v((unsigned)persistent_grid(p->M, (int64_t)q_t * g256::BN2, fc, cus));
-    const int lds_b = g256::LDS_BYTES + ROPE_LDS_BYTES;
-    if (p->dtype == OVG_BF16) {
-      int ok = allow_big_lds(qkv256p_kernel<bf16_t, false>, lds_b);
-      if (ok == OVG_OK) ok = allow_big_lds(qkv256p_kernel<bf16_t, true>, lds_b);
-      if (ok != OVG_OK) return ok;
-      OVG_LAUNCH((qkv256p_kernel<bf16_t, false>), grid_qk, dim3(512), lds_b, st, *p, qk_b, qk_c | (TILE_GROUP256 << 16), fc);
-      if (p->part != 2) OVG_LAUNCH((qkv256p_kernel<bf16_t, true>), grid_v, dim3(512), lds_b, st, *p, 2 * q_t, q_t | (TILE_GROUP256 << 16), fc);
-    } else {
-      int ok = allow_big_lds(qkv256p_kernel<f16_t, false>, lds_b);
-      if (ok == OVG_OK) ok = allow_big_lds(qkv256p_kernel<f16_t, true>, lds_b);
-      if (ok != OVG_OK) return ok;
-      OVG_LAUNCH((qkv256p_kernel<f16_t, false>), grid_qk, dim3(512), lds_b, st, *p, qk_b, qk_c | (TILE_GROUP256 << 16), fc);
-      if (p->part != 2) OVG_LAUNCH((qkv256p_kernel<f16_t, true>), grid_v, dim3(512), lds_b, st, *p, 2 * q_t, q_t | (TILE_GROUP256 << 16), fc);
-    }
-    OVG_CHECK_LAUNCH();
-    return OVG_OK;
-  }
-#endif
+  if (big < 0) return OVG_E_ARG;
   if (big) {
     const int q_t = OVG_C / g256::BN2, all_t = 3 * OVG_C / g256::BN2;
     const int ntb = p->part == 1 ? q_t : 0;
     const int ntc = p->part == 0 ? all_t : (p->part == 1 ? all_t - q_t : q_t);
     const dim3 grid2((unsigned)(((p->M + g256::BM2 - 1) / g256::BM2) * ntc));
     const int ntg2 = ntc | (TILE_GROUP256 << 16);
-#ifdef OVG_LAB_GEMM
-    if (p->dtype == OVG_BF16 && (p->tile & OVG_TILE_DMA_M)) {
-      const int ok = allow_big_lds(qkv256_kernel<bf16_t, false, true>, g256::LDS_BYTES + ROPE_LDS_BYTES);
-      if (ok != OVG_OK) return ok;
-      OVG_LAUNCH((qkv256_kernel<bf16_t, false, true>), grid2, dim3(512), g256::LDS_BYTES + ROPE_LDS_BYTES, st, *p, ntb, ntg2);
-    } else if (p->dtype == OVG_F16 && (p->tile & OVG_TILE_DMA_M)) {
-      const int ok = allow_big_lds(qkv256_kernel<f16_t, false, true>, g256::LDS_BYTES + ROPE_LDS_BYTES);
-      if (ok != OVG_OK) return ok;
-      OVG_LAUNCH((qkv256_kernel<f16_t, false, true>), grid2, dim3(512), g256::LDS_BYTES + ROPE_LDS_BYTES, st, *p, ntb, ntg2);
-    } else
-#endif
     if (p->dtype == OVG_BF16) {
       const int ok = allow_big_lds(qkv256_kernel<bf16_t>, g256::LDS_BYTES + ROPE_LDS_BYTES);
       if (ok != OVG_OK) return ok;

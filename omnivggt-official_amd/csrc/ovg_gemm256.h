@@ -1,34 +1,41 @@
-// 256 x 256 ping-pong GEMM main loop for the 16-bit modes (included by ovg_gemm.hip).
+// 256 x 256 GEMM main loop for the 16-bit modes (included by ovg_gemm.hip): the "free-running" loop of round 6.
 //
-// Why: the 128 x 128 kernels are bound by the L2 -> LDS path, not by the matrix pipe (ablation
-// builds: loads removed -> 1.2-1.3 PFLOP/s, MFMAs removed -> 93 % of the full time): 64 FLOP per
-// staged byte with at most 64 KB in flight per CU. This loop doubles the FLOP per staged byte
-// (256 x 256 tile), keeps three k-stages (96 KB per CU) of LDS-DMA in flight behind COUNTED
-// vmcnt waits (never 0 in steady state), and runs the two waves of every SIMD in antiphase.
+// Why a 256 x 256 tile: the 128 x 128 kernels are bound by the L2 -> LDS path, not by the matrix pipe (ablation builds: loads removed ->
+// 1.2-1.3 PFLOP/s, MFMAs removed -> 93 % of the full time): 64 FLOP per staged byte with at most 64 KB in flight per CU. This tile doubles the
+// FLOP per staged byte and keeps three k-stages (96 KB per CU) of LDS-DMA in flight behind COUNTED vmcnt waits (never 0 in steady state).
 //
-//   workgroup  512 threads = 8 waves as 4(n) x 2(m); wave tile 64(n) x 128(m) = acc[4][8] (128 VGPRs);
-//              1 workgroup per CU (2 waves per SIMD, 256 VGPRs each)
-//   k stage    32 elements = 64 B per row: W tile 256 x 64 B + X tile 256 x 64 B = 32 KB; 4-slot ring
-//              = 128 KB LDS. With 64-byte rows a 16-row MFMA fragment is 1 KB contiguous in LDS and the
-//              DMA image is lane-linear (lane l -> row l/4, slot l%4). ds_read_b128 is serviced in the
-//              lane groups {0-3,12-15,20-27}, ... (MI355X_MICROARCH.md LDS table), which makes the plain
-//              image 2-way conflicted (PMC: SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE); slot =
-//              chunk ^ swz((row >> 2) & 3), swz = {0,2,3,1}, applied to the DMA source chunk and to the
-//              fragment reads, is conflict-free for all four groups.
-//   ping-pong  group = wave / 4 (the two waves that share a SIMD are in different groups). Per stage
-//              a wave runs an L section (12 ds_read_b128 of tile t, 4 global_load_lds of tile t+3) and
-//              an M section (32 MFMAs under s_setprio 1). Group 1 is one barrier behind group 0, so
-//              between any two consecutive workgroup barriers one group is in M and the other in L:
-//              the matrix pipe of every SIMD always has exactly one wave feeding it.
+//   workgroup  512 threads = 8 waves as 4(n) x 2(m); wave tile 64(n) x 128(m) = acc[4][8] (128 VGPRs); 1 workgroup per CU (2 waves per SIMD)
+//   k stage    32 elements = 64 B per row: W tile 256 x 64 B + X tile 256 x 64 B = 32 KB; 4-slot ring = 128 KB LDS. With 64-byte rows a 16-row
+//              MFMA fragment is 1 KB contiguous in LDS and the DMA image is lane-linear (lane l -> row l/4, slot l%4). ds_read_b128 is serviced in
+//              the lane groups {0-3,12-15,20-27}, ... (MI355X_MICROARCH.md LDS table), which makes the plain image 2-way conflicted (PMC:
+//              SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE); slot = chunk ^ swz((row >> 2) & 3), swz = {0,2,3,1}, applied to the DMA source
+//              chunk and to the fragment reads, is conflict-free for all four groups.
 //
-//     G0:  P  L(0) b0 M(0)+w(1) b1 L(1) b2 M(1)+w(2) b3 ...
-//     G1:  P  b0 L(0)+w(1) b1 M(0) b2 L(1)+w(2) b3 M(1) ...          w(t) = counted vmcnt for tile t
+// Rounds 1-5 ran this tile as a PING-PONG loop (the guide's 8-phase idea): a wave's stage was L (12 ds_read_b128 + 4 LDS-DMA requests, ~600
+// cycles) then M (32 MFMAs, ~540 cycles) with TWO workgroup barriers, the partner wave of the SIMD one barrier behind, so that one of the two
+// always fed the matrix pipe. A wave's own time line was serial (L + M). Round 6 (profiles/r06_gemm_free_running_ab.txt): every wave
+// software-pipelines its OWN stream -- while the 32 MFMAs of k-stage t issue, the 12 fragment reads of k-stage t + 1 are interleaved between
+// them (one X fragment behind each group of four MFMAs, into registers a previous group released; the four W fragments double-buffered) and
+// the four LDS-DMA requests of k-stage t + 4 sit behind groups 1 / 3 / 5 / 7 -- so a wave's time line is MFMA issue plus a handful of issue
+// slots, the two waves of a SIMD simply share the pipe, and there is ONE barrier per k-stage. Bit-identical results (same k order, same
+// accumulator layout: every epilogue is shared), +3 % on every shape (4096^3: 1326 -> 1366 TFLOP/s; fc1 at 64 views 930 -> 958).
 //
-//   RAW (DMA -> ds_read): every wave passes its own w(t) before barrier b(2t-1); the first reader of
-//        tile t (G0's L(t)) starts after b(2t-1).
-//   WAR (ds_read -> DMA into the same slot): tile t+3 reuses the slot of tile t-1 and is issued in L(t),
-//        i.e. after b(2t-1); G0's reads of t-1 were consumed by M(t-1) before b(2t-1), G1's L(t-1)
-//        ends with lgkmcnt(0) before b(2t-1).
+//   C(t):  lgkmcnt(0) [fragments of stage t complete]  ->  counted vmcnt [own DMA pieces of stage t + 1 landed]  ->  s_barrier B(t)
+//          ->  8 x { 4 MFMAs of stage t ; 1-2 ds_read_b128 of stage t + 1 ; every other group: one LDS-DMA request of stage t + 4 }
+//
+//   RAW (DMA -> ds_read): stage t + 1 is read in C(t), behind B(t); every wave passed its own counted wait for stage t + 1 before B(t)
+//        ("read a staged buffer one phase AFTER the wait that retires it", cdna_hip_programming.md).
+//   WAR (ds_read -> DMA into the same slot): stage t + 4 reuses the slot of stage t; its requests are issued behind B(t), and every wave's
+//        reads of stage t (issued in C(t - 1)) were retired by the lgkmcnt(0) in front of B(t).
+//   Ring: stages t + 1 (landed), t + 2, t + 3 (in flight) and the new request t + 4: three k-stages of look-ahead.
+//
+// DMA addressing: a workgroup-uniform 64-bit base per operand (SGPR pair, advanced by one scalar add per k-stage) + a 32-bit byte offset per
+// request and lane (row inside the tile x leading dimension + swizzled chunk; < 2^32 because it spans one tile only).
+//
+// Measured and not kept (same log): the four requests at the head of the stage (-2 %), sched_group_barrier hints instead of the pinned
+// order (-3 %), and a 256(n) x 128(m) tile of 4 waves with a 3-slot ring of 24 KB stages at TWO workgroups per CU (the r02 idea on this loop:
+// prologue / epilogue / barrier waits of one workgroup under the other's MFMAs) -- its main loop reaches 1112 TFLOP/s on 4096^3 (r02's form:
+// 966) against 1366, and on the K = 1024 shapes the hidden epilogue only buys that back (fc1 -2.5 %, QKV / proj +-0, fc2 -10 %).
 #pragma once
 
 namespace g256 {
@@ -36,14 +43,13 @@ namespace g256 {
 constexpr int BM2 = 256, BN2 = 256, ROWB = 64, SLOTS = 4;
 constexpr int W_TILE = BN2 * ROWB, X_TILE = BM2 * ROWB, STAGE_B = W_TILE + X_TILE;
 constexpr int LDS_BYTES = SLOTS * STAGE_B;
+constexpr int NP = 4;                                    // LDS-DMA requests per wave and k-stage: 2 x 16 rows of W, 2 x 16 rows of X
 
 OVG_DEV int swz64(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }   // {0,2,3,1}[(row>>2)&3]
 
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-OVG_DEV void wait_tiles_in_flight(int n) {     // leave at most n k-stages (4 DMA instructions each) outstanding
-  if (n >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+OVG_DEV void wait_stages_in_flight(int n) {     // leave at most n k-stages (NP requests each) of this wave outstanding
+  if (n >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (n == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if (n == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -52,14 +58,9 @@ OVG_DEV void wait_tiles_in_flight(int n) {     // leave at most n k-stages (4 DM
 // operands trade places and every 16 x 16 block comes out transposed: acc[nt][mt][r] = C[n = .. + 16 nt + (lane & 15)][m = .. + 16 mt + 4g + r]
 // (the V^T tiles of the QKV projection: a lane then owns 4 CONSECUTIVE tokens of one feature = one 8-byte store)
 // X3 (OVG_F16X2): operands are (hi, lo) plane pairs and the ring streams 3 nk virtual k-stages -- x_lo * w_hi, x_hi * w_lo, x_hi * w_hi --
-// whose source planes are chosen per stage in stage(); everything else (ring, waits, ping-pong) is unchanged.
-// DMA_M (round 5): the four LDS-DMA requests of a k-stage are issued INSIDE the M section, one behind every eighth MFMA, instead of in the
-// L section. Timeline + issue-cost arithmetic (profiles/r05_gemm_timeline.txt, MI355X_MICROARCH.md "LDS-DMA piece issue cost"): an L section is
-// 12 ds_read_b128 + 4 DMA requests at 100-185 cycles each = ~600 cycles, LONGER than the 544 cycles of the partner's 32 MFMAs, so the
-// barrier interval was paced by the loads; among MFMAs a request costs ~60 cycles of issue that the matrix pipe covers. The request for
-// k-stage t + 3 moves from L(t) to M(t) (later for both groups: the WAR argument above holds a fortiori); group 1's counted wait w(t + 1),
-// which sits in L(t) in front of M(t), now sees requests up to k-stage t + 2 only and leaves one stage in flight instead of two.
-template <typename T, bool SWAP = false, bool X3 = false, bool DMA_M = false>
+// whose source planes are chosen per stage; everything else (ring, waits) is unchanged.
+// Returns behind a workgroup barrier with every DMA waited for and every fragment read retired: the ring is idle (the epilogues stage through it).
+template <typename T, bool SWAP = false, bool X3 = false>
 OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict__ W, int64_t ldw,
                       int M, int N, int K, int m0, int n0, unsigned char* lds, f32x4 (&acc)[4][8],
                       const T* __restrict__ Xlo = nullptr, const T* __restrict__ Wlo = nullptr) {
@@ -69,24 +70,26 @@ OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict_
   const int wn = wave & 3, wm = wave >> 2;
   const int g = lane >> 4, lr = lane & 15;
 
-  // DMA sources: wave w stages rows [32w, 32w + 32) of both tiles, 16 rows per instruction
-  const unsigned char* wg[2];
-  const unsigned char* xg[2];
+  // DMA sources: wave w stages rows [32w, 32w + 32) of both tiles, 16 rows per request; rows past the end of a tensor re-read its last row
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(W + (int64_t)n0 * ldw);
+  const unsigned char* xbase = reinterpret_cast<const unsigned char*>(X + (int64_t)m0 * ldx);
+  uint32_t wg[2], xg[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = wave * 32 + i * 16 + (lane >> 2);
-    int wr = n0 + row; wr = wr < N ? wr : N - 1;
-    int xr = m0 + row; xr = xr < M ? xr : M - 1;
-    const int ch = (lane & 3) ^ swz64(row);                     // source chunk for linear LDS slot (lane & 3)
-    wg[i] = reinterpret_cast<const unsigned char*>(W + (int64_t)wr * ldw) + ch * 16;
-    xg[i] = reinterpret_cast<const unsigned char*>(X + (int64_t)xr * ldx) + ch * 16;
+    const int wr = n0 + row < N ? row : N - 1 - n0;
+    const int xr = m0 + row < M ? row : M - 1 - m0;
+    const uint32_t ch = (uint32_t)(((lane & 3) ^ swz64(row)) * 16);              // source chunk for linear LDS slot (lane & 3)
+    wg[i] = (uint32_t)wr * (uint32_t)(ldw * 2) + ch;
+    xg[i] = (uint32_t)xr * (uint32_t)(ldx * 2) + ch;
   }
   const int nk1 = (K * 2) / ROWB;
+  const int nk = X3 ? 3 * nk1 : nk1;                                             // even: K % 64 == 0 (ovg_linear / ovg_qkv check it)
   const int64_t dxl = X3 ? reinterpret_cast<const unsigned char*>(Xlo) - reinterpret_cast<const unsigned char*>(X) : 0;
   const int64_t dwl = X3 ? reinterpret_cast<const unsigned char*>(Wlo) - reinterpret_cast<const unsigned char*>(W) : 0;
-  auto stage = [&](int kt) {
-    unsigned char* wb = lds + (kt & (SLOTS - 1)) * STAGE_B + wave * 32 * ROWB;   // wave-uniform destinations
-    unsigned char* xb = wb + W_TILE;
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+  auto stage_piece = [&](int kt, int j) {          // request j = 0..3 of k-stage kt: W rows 0-15, W rows 16-31, X rows 0-15, X rows 16-31 of this wave's 32
+    const uint32_t sb = lds_base + (kt & (SLOTS - 1)) * STAGE_B + wave * 32 * ROWB;
     int64_t xo = (int64_t)kt * ROWB, wo = xo;
     if constexpr (X3) {
       const int pass = kt >= 2 * nk1 ? 2 : (kt >= nk1 ? 1 : 0);
@@ -94,105 +97,66 @@ OVG_DEV void mainloop(const T* __restrict__ X, int64_t ldx, const T* __restrict_
       xo = kb + (pass == 0 ? dxl : 0);
       wo = kb + (pass == 1 ? dwl : 0);
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(wg[i] + wo), (lptr_t)(wb + i * 16 * ROWB), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(xg[i] + xo), (lptr_t)(xb + i * 16 * ROWB), 16, 0, 0);
-    }
+    if (j < 2) lds_dma16_s(wbase + wo, wg[j], sb + j * 16 * ROWB);
+    else lds_dma16_s(xbase + xo, xg[j - 2], sb + W_TILE + (j - 2) * 16 * ROWB);
   };
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = X3 ? 3 * nk1 : nk1;
   const int frag_off = lr * ROWB + (g ^ swz64(lr)) * 16;
-  const int w_off = wn * 64 * ROWB + frag_off, x_off = W_TILE + wm * 128 * ROWB + frag_off;
-  u32x4 a[4], b[8];
-  auto read_frags = [&](int kt) {
-    const unsigned char* base = lds + (kt & (SLOTS - 1)) * STAGE_B;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const u32x4*>(base + w_off + t * 16 * ROWB);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) b[t] = *reinterpret_cast<const u32x4*>(base + x_off + t * 16 * ROWB);
-  };
-  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
-  auto stage_piece = [&](int kt, int j) {          // DMA_M: request j = 0..3 of k-stage kt (W rows 0-15, X rows 0-15, W rows 16-31, X rows 16-31 of this wave's 32)
-    const uint32_t wb = lds_base + (kt & (SLOTS - 1)) * STAGE_B + wave * 32 * ROWB;
-    int64_t xo = (int64_t)kt * ROWB, wo = xo;
-    if constexpr (X3) {
-      const int pass = kt >= 2 * nk1 ? 2 : (kt >= nk1 ? 1 : 0);
-      const int64_t kb = (int64_t)(kt - pass * nk1) * ROWB;
-      xo = kb + (pass == 0 ? dxl : 0);
-      wo = kb + (pass == 1 ? dwl : 0);
-    }
-    const int i = j >> 1;
-    if (j & 1) lds_dma16(xg[i] + xo, wb + W_TILE + i * 16 * ROWB);
-    else lds_dma16(wg[i] + wo, wb + i * 16 * ROWB);
-  };
-  auto mfmas = [&](int kt_req = -1) {              // kt_req >= 0 (DMA_M): k-stage to request between the MFMAs
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-#pragma unroll
-      for (int mt = 0; mt < 8; ++mt) {
-        if constexpr (SWAP) TT<T>::mma(acc[nt][mt], b[mt], a[nt]);
-        else TT<T>::mma(acc[nt][mt], a[nt], b[mt]);
-        if constexpr (DMA_M) {
-          if (mt == 3) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt_req >= 0) stage_piece(kt_req, nt);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-    }
-    __builtin_amdgcn_s_setprio(0);
-  };
-  auto in_flight_after = [&](int t) {   // k-stages issued beyond tile t when the wave has staged up to tile min(t + 2, nk - 1)
-    const int last = (t + 2) < (nk - 1) ? (t + 2) : (nk - 1);
-    return last - t;
-  };
+  const unsigned char* wfrag = lds + wn * 64 * ROWB + frag_off;
+  const unsigned char* xfrag = lds + W_TILE + wm * 128 * ROWB + frag_off;
+  u32x4 a0[4], a1[4], b[8];
 
-  for (int s = 0; s < 3; ++s)
-    if (s < nk) stage(s);
-  wait_tiles_in_flight(in_flight_after(0));
-  __builtin_amdgcn_s_barrier();                      // P: tile 0 visible to every wave (NOT __syncthreads: its fence drains vmcnt to 0)
+  for (int s = 0; s < SLOTS; ++s)
+    if (s < nk)
+      for (int j = 0; j < NP; ++j) stage_piece(s, j);
+  wait_stages_in_flight((nk < SLOTS ? nk : SLOTS) - 1);      // stage 0 landed, the others stay in flight
+  __builtin_amdgcn_s_barrier();                              // NOT __syncthreads: its fence drains vmcnt to 0
   tl_mark(1);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) a0[t] = *reinterpret_cast<const u32x4*>(wfrag + t * 16 * ROWB);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) b[t] = *reinterpret_cast<const u32x4*>(xfrag + t * 16 * ROWB);
 
-  if (wm == 0) {
-    for (int t = 0; t < nk; ++t) {
-      read_frags(t);                                 // L(t)
-      if constexpr (!DMA_M) { if (t + 3 < nk) stage(t + 3); }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();                  // b(2t)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (DMA_M) mfmas(t + 3 < nk ? t + 3 : -1); else mfmas();   // M(t)
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < nk) wait_tiles_in_flight(in_flight_after(t + 1));   // w(t+1): stages issued so far reach t+3
-      __builtin_amdgcn_s_barrier();                  // b(2t+1)
-    }
-    __builtin_amdgcn_s_barrier();                    // pairs with group 1's last barrier
-  } else {
-    __builtin_amdgcn_s_barrier();                    // b0: one barrier behind group 0
-    for (int t = 0; t < nk; ++t) {
-      read_frags(t);                                 // L(t)
-      if constexpr (!DMA_M) { if (t + 3 < nk) stage(t + 3); }
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < nk) {                              // w(t+1); DMA_M: requests so far reach k-stage t + 2 (M(t - 1))
-        if constexpr (DMA_M) wait_tiles_in_flight(((t + 2) < (nk - 1) ? (t + 2) : (nk - 1)) - (t + 1));
-        else wait_tiles_in_flight(in_flight_after(t + 1));
+  // one k-stage: MFMAs of stage t on (acur, b), fragment reads of stage t + 1 into (anxt, b), DMA requests of stage t + 4.
+  // infl: k-stages that may stay in flight behind stage t + 1 at the wait (-1: stage t + 1 does not exist)
+  auto body = [&](int t, const u32x4 (&acur)[4], u32x4 (&anxt)[4], bool dma, int infl) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (infl >= 0) wait_stages_in_flight(infl);
+    __builtin_amdgcn_s_barrier();                              // B(t)
+    __builtin_amdgcn_sched_barrier(0);
+    const int so = ((t + 1) & (SLOTS - 1)) * STAGE_B;
+    const unsigned char* wn_ = wfrag + so;
+    const unsigned char* xn_ = xfrag + so;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        if constexpr (SWAP) TT<T>::mma(acc[nt][mt], b[mt], acur[nt]);
+        else TT<T>::mma(acc[nt][mt], acur[nt], b[mt]);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                  // b(2t+1)
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (DMA_M) mfmas(t + 3 < nk ? t + 3 : -1); else mfmas();   // M(t)
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();                  // b(2t+2)
+      if (mt < 4) anxt[mt] = *reinterpret_cast<const u32x4*>(wn_ + mt * 16 * ROWB);
+      b[mt] = *reinterpret_cast<const u32x4*>(xn_ + mt * 16 * ROWB);
+      __builtin_amdgcn_sched_barrier(0);                       // order pinned group by group (hints alone measured -3 %)
+      if (dma && (mt & 1)) { stage_piece(t + SLOTS, mt >> 1); __builtin_amdgcn_sched_barrier(0); }
     }
-  }
-}
+  };
 
+  int t = 0;
+  for (; t + SLOTS + 1 < nk; t += 2) {                         // steady state: stages t + 1 .. t + 3 requested, t + 4 / t + 5 follow
+    body(t, a0, a1, true, SLOTS - 2);
+    body(t + 1, a1, a0, true, SLOTS - 2);
+  }
+  for (; t + 1 < nk; t += 2) {                                 // drain: no new requests
+    const int i0 = nk - 2 - t, i1 = nk - 3 - t;
+    body(t, a0, a1, false, i0 < SLOTS - 2 ? i0 : SLOTS - 2);
+    body(t + 1, a1, a0, false, i1 < 0 ? -1 : (i1 < SLOTS - 2 ? i1 : SLOTS - 2));
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the look-ahead reads of the last stage (unused) before the ring is reused
+  __builtin_amdgcn_s_barrier();
+}
 
 }  // namespace g256

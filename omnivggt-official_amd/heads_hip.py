@@ -157,7 +157,7 @@ class HipDPTHead:
             y = ops.upsample(u, size[0], size[1], dtype)
         y = ops.conv(y, P["oc1"][0], P["oc1"][1], dtype, 128, ksize=3)
         pos = self._postab(128, ph * ps, pw * ps, W, H, dev)
-        if self.fused_tail and ops.dpt_tail_supported(y, dtype):
+        if self.fused_tail and ops.dpt_tail_supported(y, dtype, ph * ps, pw * ps):
             # upsample + position embedding + output_conv2 + activation in one launch (csrc/ovg_dpt_tail.h): the image-resolution maps stay on chip
             return ops.dpt_tail(y, ph * ps, pw * ps, dtype, pos, P["oc2a"][0], P["oc2a"][1], P["oc2b"][0], P["oc2b"][1], head.activation)
         y = ops.upsample(y, ph * ps, pw * ps, dtype, pos=pos)

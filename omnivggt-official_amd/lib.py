@@ -14,10 +14,8 @@ OVG_BF16, OVG_F16, OVG_F32, OVG_F16X2 = 0, 1, 2, 3
 EPI_STORE, EPI_GELU, EPI_RES, EPI_PATCH = 0, 1, 2, 3
 OVG_MAX_SEG = 8
 KV_TILE = 64
-ABI_VERSION = 10
+ABI_VERSION = 11
 TILE_AUTO, TILE_128, TILE_256 = 0, 1, 2
-TILE_DMA_M, TILE_256M = 8, 10                                   # flag / 256 x 256 with the DMA requests inside the M sections
-TILE_256P = 4                                                  # persistent 256 x 256 (ovg_gemm256p.h): plain 16-bit dtypes, N % 256 == 0, K % 128 == 0
 TILE_R02_EPILOGUE, TILE_128X, TILE_256X = 16, 17, 18      # A/B flag (r02 epilogue forms) OR-ed onto a tile selector
 
 ERRORS = {0: "OVG_OK", -1: "OVG_E_ARG", -2: "OVG_E_DTYPE", -3: "OVG_E_LAUNCH", -4: "OVG_E_UNSUPPORTED"}

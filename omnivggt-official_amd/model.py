@@ -75,7 +75,10 @@ class OmniVGGT(nn.Module, _HubMixin):
             return {name: fn() for name, fn in jobs}
         cur = torch.cuda.current_stream()
         dev = cur.device
-        streams = _HEAD_STREAMS.setdefault(str(dev), [torch.cuda.Stream(device=dev) for _ in range(3)])   # per device, shared by all models of the process (not model state: nothing to copy / pickle)
+        key = str(dev)
+        if key not in _HEAD_STREAMS:                   # created once per device, shared by all models of the process (not model state: nothing to copy / pickle)
+            _HEAD_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(3)]
+        streams = _HEAD_STREAMS[key]
         fork = torch.cuda.Event()
         fork.record(cur)
         res = {}
@@ -99,10 +102,28 @@ class OmniVGGT(nn.Module, _HubMixin):
             return self._hip_cam(cam_tokens, dtype=dt)
         return self.camera_head(cam_tokens)
 
-    def _dpt(self, which, head, tokens, imgs32, patch_start_idx):
+    # activation bytes of ONE frame inside one HIP DPT head at 518 x 518 in a 16-bit dtype (64 frames measure ~17 GB); f32 heads hold twice that
+    _DPT_BYTES_PER_FRAME_16 = 0.28e9
+
+    def _frames_per_pass(self, imgs32, dt, concurrent):
+        """`dpt_frames_chunk` is an upper bound sized for the 288 GB of an MI355X; the pass actually taken also fits HALF of the memory that is
+        free right now (both DPT heads at once when they run concurrently; blocks freed on a side stream stay in that stream's allocator pool), so a
+        smaller part, or a process that shares its GPU, degrades to the reference's 8 frames per pass (dpt_head.py:133,163) instead of failing."""
+        cap = int(self.dpt_frames_chunk)
+        if not imgs32.is_cuda or cap <= 8:
+            return cap
+        free, _ = torch.cuda.mem_get_info(imgs32.device)
+        px = imgs32.shape[-1] * imgs32.shape[-2] / float(518 * 518)
+        per_frame = self._DPT_BYTES_PER_FRAME_16 * px * (1 if dt in (torch.bfloat16, torch.float16) else 2) * (2 if concurrent else 1)
+        fit = int(0.5 * free / per_frame)
+        while cap > 8 and cap > fit:
+            cap //= 2
+        return max(cap, 8)
+
+    def _dpt(self, which, head, tokens, imgs32, patch_start_idx, concurrent=False):
         dt = self.head_dtype or L.head_dtype(self.aggregator.compute_dtype)
         if self.hip_heads and imgs32.is_cuda and (dt in (torch.bfloat16, torch.float16) or self.hip_heads_f32):
-            return self._hip_dpt[which](tokens, imgs32, patch_start_idx, frames_chunk_size=self.dpt_frames_chunk, dtype=dt)   # f32: exact-f32 MFMA convolutions (r03)
+            return self._hip_dpt[which](tokens, imgs32, patch_start_idx, frames_chunk_size=self._frames_per_pass(imgs32, dt, concurrent), dtype=dt)   # f32: exact-f32 MFMA convolutions (r03)
         return head(tokens, images=imgs32, patch_start_idx=patch_start_idx)
 
     def set_compute_dtype(self, dtype):
@@ -190,13 +211,14 @@ class OmniVGGT(nn.Module, _HubMixin):
                 cam_tokens = [shard.gather_views(tokens[-1][:, :, :1].contiguous(), parts)]
                 imgs32 = imgs32[:, lo:hi]
             jobs = []
+            conc = bool(self.concurrent_heads and self.hip_heads and not sharded and imgs32.is_cuda)
             if self.camera_head is not None:
                 jobs.append(("camera", lambda: self._camera(cam_tokens)))
             if self.depth_head is not None:
-                jobs.append(("depth", lambda: self._dpt("depth", self.depth_head, tokens, imgs32, patch_start_idx)))
+                jobs.append(("depth", lambda: self._dpt("depth", self.depth_head, tokens, imgs32, patch_start_idx, conc)))
             if self.point_head is not None:
-                jobs.append(("point", lambda: self._dpt("point", self.point_head, tokens, imgs32, patch_start_idx)))
-            res = self._run_heads(jobs, concurrent=self.concurrent_heads and self.hip_heads and not sharded and imgs32.is_cuda)
+                jobs.append(("point", lambda: self._dpt("point", self.point_head, tokens, imgs32, patch_start_idx, conc)))
+            res = self._run_heads(jobs, concurrent=conc)
             if "camera" in res:
                 out["pose_enc"], out["pose_enc_list"] = res["camera"][-1], res["camera"]
             if "depth" in res:

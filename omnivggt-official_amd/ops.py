@@ -405,9 +405,20 @@ def upsample(x, OH, OW, dtype, pos=None):
     return out
 
 
-def dpt_tail_supported(x, dtype):
-    """The one-launch output stage (ovg_dpt_tail) exists for the plain 16-bit dtypes and the model's 128-channel map."""
-    return dtype in (torch.bfloat16, torch.float16) and x.shape[-1] == 128
+def dpt_tail_supported(x, dtype, OH=None, OW=None):
+    """The one-launch output stage (ovg_dpt_tail) exists for the plain 16-bit dtypes and the model's 128-channel map. Mirrors every
+    host-side limit of the C entry (csrc/ovg_head.hip: ovg_dpt_tail) that answers OVG_E_UNSUPPORTED / OVG_E_ARG for a shape the three-launch
+    form still serves -- one source image within 32-bit element offsets, an output of at least 2 x 2 pixels, 16-byte aligned rows --
+    so that callers fall back to upsample -> conv -> dpt_out instead of raising (round-5 advisor)."""
+    if dtype not in (torch.bfloat16, torch.float16) or x.dim() != 4 or x.shape[-1] != 128:
+        return False
+    n, H, W, c = x.shape
+    ldx = x.stride(2)
+    if H * W * ldx >= (1 << 31) or ldx % 8 or (x.data_ptr() & 15):
+        return False
+    if OH is not None and (OH <= 1 or OW <= 1):
+        return False
+    return True
 
 
 def dpt_tail(x, OH, OW, dtype, pos, w1, b1, w2, b2, activation):

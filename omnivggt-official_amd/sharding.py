@@ -302,7 +302,10 @@ class ViewSharding:
             if reserve and self.world > 1 and hasattr(ex, "cus"):
                 dev_cus = (torch.cuda.get_device_properties(device).multi_processor_count
                            if (torch.cuda.is_available() and str(device).startswith("cuda")) else DEVICE_CUS)
-                ex.cus = available_cus(self.world, dev_cus)
+                # the budget feeds head_groups(), i.e. HOW MANY grouped exchanges a rank issues per layer: ranks that read different
+                # environments (NCCL_MAX_NCHANNELS) or CU counts would issue different numbers of collectives and hang (round-5 advisor).
+                # Agree once, here -- every rank creates its executor at the same point of its first forward: the MINIMUM over the ranks.
+                ex.cus = self._agree_min(available_cus(self.world, dev_cus), device)
             self._executors[key] = ex
         return self._executors[key]
 
@@ -381,6 +384,72 @@ class ViewSharding:
             return self._Done()
         return done
 
+    def _agree_min(self, value, device):
+        """One integer, the minimum over the ranks of the group (a collective: call it at the same point on every rank)."""
+        on_dev = self._nccl() and torch.cuda.is_available() and str(device).startswith("cuda")
+        t = torch.tensor([int(value)], dtype=torch.int64, device=device if on_dev else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return int(t.item())
+
+    def attention_cus_probe(self, agg, S, device, cus_values, reps=3):
+        """bench.py pre-flight at N > 1 (round-5 review item 7): time THIS rank's global-attention launch of the current exchange form
+        with its launch plan sized for each CU budget in `cus_values` -- alone, and with one layer's inbound exchange in flight beside
+        it -- so that the first multi-GPU log shows whether reserving CUs for RCCL's channels (available_cus) helps, hurts or does nothing.
+        Returns {cus: {"alone_ms", "under_exchange_ms"}} (MAX over ranks), or None for executors without a CU budget (CPU tests).
+        Every rank issues the same collectives in the same order; nothing here changes the executor's state afterwards."""
+        ex = self.executor(agg, device)
+        if not hasattr(ex, "cus") or not (torch.cuda.is_available() and str(device).startswith("cuda")):
+            return None
+        mode = resolve_mode(self.last_mode or self.mode, S, self.world, _parity_mode(agg))
+        P = agg.tokens_per_view
+        parts = partition(S, self.world)
+        lo, hi = parts[self.rank]
+        n = (hi - lo) * P
+        W, hpr = self.world, 16 // self.world if 16 % self.world == 0 else 0
+        if mode == "heads":
+            _, ws_g, xb = ex.heads_workspaces(hi - lo, P, W)
+            g = xb["groups"][0]
+            sl = [slice(r * hpr + g["h0"], r * hpr + g["h0"] + g["gs"]) for r in range(W)]
+            launch = lambda: ex.head_attention(g["q"], g["k"], g["vt"], g["o"], n, W)
+            exchange = lambda: [self._exchange_many([(list(g["q"].unbind(0)), [ws_g.q[s_] for s_ in sl]), (list(g["k"].unbind(0)), [ws_g.k[s_] for s_ in sl]),
+                                                     (list(g["vt"].unbind(0)), [ws_g.vt[s_] for s_ in sl])], async_op=True)]
+        else:
+            _, ws_g = ex.workspaces(hi - lo, max(h - l for l, h in parts), P)
+            kg, vg = ex.gather_buffers(ws_g, W)
+            counts = [(h - l) * P for l, h in parts]
+            launch = lambda: ex.attend_remote(0, ws_g, kg, vg, counts, self.rank, n)
+            exchange = lambda: [self._all_gather(kg.flatten(0, 1), ex._wire(ws_g.k), async_op=True), self._all_gather(vg.flatten(0, 1), ex._wire(ws_g.vt), async_op=True)]
+        saved, table = ex.cus, {}
+        dev_cus = torch.cuda.get_device_properties(device).multi_processor_count
+        try:
+            for c in cus_values:
+                ex.cus = 0 if c >= dev_cus else int(c)
+                launch()                                               # plan + split workspace for this budget (cached per budget)
+                torch.cuda.synchronize(device)
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                e[0].record()
+                for _ in range(reps):
+                    launch()
+                e[1].record()
+                torch.cuda.synchronize(device)
+                alone = e[0].elapsed_time(e[1]) / reps
+                under = 0.0
+                for _ in range(reps):
+                    works = exchange()
+                    e[0].record()
+                    launch()
+                    e[1].record()
+                    for w in works:
+                        w.wait()
+                    torch.cuda.synchronize(device)
+                    under += e[0].elapsed_time(e[1]) / reps
+                t = torch.tensor([alone, under], dtype=torch.float64, device=device if self._nccl() else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                table[int(c)] = {"alone_ms": round(float(t[0]), 4), "under_exchange_ms": round(float(t[1]), 4)}
+        finally:
+            ex.cus = saved
+        return table
+
     def _all_reduce_max(self, t):
         if not self._nccl() and t.is_cuda:
             tmp = t.cpu()
@@ -428,7 +497,15 @@ class ViewSharding:
     def forward(self, agg, images, extrinsics, intrinsics, depth, mask, depth_gt_index, camera_gt_index):
         B, S = images.shape[:2]
         if B != 1:
-            raise NotImplementedError("view sharding needs B == 1 (views must be a contiguous slice of one sequence)")
+            # (B, S, ...) batches (omnivggt.py:31-32): every batch entry is its own global sequence (aggregator.py:317-318), its own depth
+            # statistics and its own camera frame, and the index lists are shared -- so the view axis of EACH entry is sharded exactly like a
+            # B = 1 call, one entry after the other (same collectives in the same order on every rank), and the per-entry outputs are stacked.
+            # An entry's S views already occupy every rank; running the entries concurrently would only interleave their exchanges.
+            def entry(t, b):
+                return None if t is None else t[b:b + 1]
+            per = [self.forward(agg, images[b:b + 1], entry(extrinsics, b), entry(intrinsics, b), entry(depth, b), entry(mask, b),
+                                depth_gt_index, camera_gt_index)[0] for b in range(B)]
+            return [torch.cat([o[i] for o in per], dim=0) for i in range(len(per[0]))], agg.patch_start_idx
         if S < self.world:
             raise ValueError("fewer views (%d) than ranks (%d)" % (S, self.world))
         if self.world > ops.L.OVG_MAX_SEG:
@@ -545,9 +622,9 @@ class ViewSharding:
         return mode
 
     def gather_views(self, local, parts):
-        """all-gather a (1, n_local, ...) tensor along the view axis (uneven shards padded)."""
+        """all-gather a (B, n_local, ...) tensor along the view axis (uneven shards padded)."""
         max_local = max(h - l for l, h in parts)
-        pad = torch.zeros((1, max_local) + tuple(local.shape[2:]), device=local.device, dtype=local.dtype)
+        pad = torch.zeros((local.shape[0], max_local) + tuple(local.shape[2:]), device=local.device, dtype=local.dtype)
         pad[:, : local.shape[1]] = local
         full = torch.empty((self.world,) + tuple(pad.shape), device=local.device, dtype=local.dtype)
         skip, self.skip_comm = self.skip_comm, False

@@ -139,8 +139,18 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--target-ms", type=float, default=20.0)
     ap.add_argument("--out", default="")
+    ap.add_argument("--alt-lib", default="", help="name of an alternate build under tools/probes/_build/ (build_alt.py) to run on instead of the product library")
     args = ap.parse_args()
     L.require_gpu()
+    if args.alt_lib:
+        import ctypes
+        alt = ctypes.CDLL(os.path.join(ROOT, "tools", "probes", "_build", args.alt_lib, "libomnivggt_hip.so"))
+        for name, (res, a) in L.SYMBOLS.items():
+            f = getattr(alt, name)
+            f.restype, f.argtypes = res, a
+        L.load()
+        L._lib = alt
+        print("running on the alternate build", args.alt_lib, flush=True)
     res = {}
     if args.what in ("attn", "all"):
         res.update(attn(args))

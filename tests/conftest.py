@@ -11,4 +11,3 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "gpu_slow: needs a real MI355X AND minutes of CPU oracle time; run once per round by the builder (-m gpu_slow)")

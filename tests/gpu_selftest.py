@@ -1083,26 +1083,6 @@ def microbench():
     return out
 
 
-def _with_lab_lib(fn):
-    """Round-5 lab GEMM forms (OVG_TILE_256P / OVG_TILE_256M) exist only in a library built with -DOVG_LAB_GEMM
-    (python tools/probes/build_alt.py lab=-DOVG_LAB_GEMM); run `fn` on it, then switch back. Only via --only."""
-    import ctypes
-    path = os.path.join(ROOT, "tools", "probes", "_build", "lab", "libomnivggt_hip.so")
-    if not os.path.exists(path):
-        print("[SKIP] no lab library at %s" % path)
-        return
-    prod = L.load()
-    lab = ctypes.CDLL(path)
-    for name, (res, args) in L.SYMBOLS.items():
-        f = getattr(lab, name)
-        f.restype, f.argtypes = res, args
-    L._lib = lab
-    try:
-        fn()
-    finally:
-        L._lib = prod
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
@@ -1123,11 +1103,11 @@ def main():
     print(L.load().ovg_build_info().decode(), torch.cuda.get_device_name(0), flush=True)
     tests = {"probe": test_probe, "layernorm": test_layernorm, "linear": lambda: test_linear(args.quick), "qkv": lambda: test_qkv(args.quick),
              "attn": lambda: test_attn(args.quick), "embed": test_embed, "block": lambda: test_block(args.quick),
-             "heads": lambda: test_heads(args.quick), "gemm256": lambda: test_gemm256(args.quick), "gemm256p": lambda: _with_lab_lib(lambda: test_gemm256(args.quick, tile=L.TILE_256P, auto_is=False)),
-             "gemm256m": lambda: _with_lab_lib(lambda: test_gemm256(args.quick, tile=L.TILE_256M, auto_is=False)), "attn_big": lambda: test_attn_big(args.quick),
+             "heads": lambda: test_heads(args.quick), "gemm256": lambda: test_gemm256(args.quick),
+             "attn_big": lambda: test_attn_big(args.quick),
              "lse_merge": test_attn_lse_merge, "camera": lambda: test_camera_head(timing=True), "f32x": lambda: test_f32x(args.quick), "fallback": test_attn_fallback_counter}
     for name, fn in tests.items():
-        if (args.only and name not in args.only.split(",")) or (not args.only and name in ("gemm256p", "gemm256m")):
+        if args.only and name not in args.only.split(","):
             continue
         t0 = time.time()
         try:

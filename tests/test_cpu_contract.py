@@ -537,9 +537,16 @@ def test_attention_launch_plan_of_the_baseline_shapes():
     for S in (9, 10):
         p = plan(16, S * P, [S * P], bf)
         assert (p["q_tile"], p["tail_q_tile"], p["main_rows"]) == (256, 128, 8192), (S, p)     # one full round of 512 slots, then 128-row tiles
-    for S, rows in ((16, 16384), (64, 81920)):                                                 # 2 / 10 full rounds of 512-row tiles on 256 CUs
+    # 512-row tiles from 2.5 rounds on: the full rounds (2 at 16 views, 10 at 64 on 256 CUs) unsplit; the rows beyond them as 128-row tiles when
+    # the caller gives no workspace (kv_splits = 1), else -- round 6 -- as 512-row tiles cut along the keys so that tail units x ranges fill whole
+    # rounds: 16 views 176 units x 4, 64 views 192 units x 8 (f32 partials for the tail rows only, padded to the 512-row tile)
+    for S, rows, s, tail_pad in ((16, 16384, 4, 5632), (64, 81920, 8, 6144)):
+        p = plan(16, S * P, [S * P], bf, kv_splits=1)
+        assert (p["q_tile"], p["tail_q_tile"], p["main_rows"], p["splits"]) == (512, 128, rows, 1), (S, p)
         p = plan(16, S * P, [S * P], bf)
-        assert (p["q_tile"], p["tail_q_tile"], p["main_rows"]) == (512, 128, rows), (S, p)
+        assert (p["q_tile"], p["tail_q_tile"], p["main_rows"], p["splits"]) == (512, 512, rows, s), (S, p)
+        assert p["part_bytes"] == s * 16 * tail_pad * 64 * 4 and p["lse_bytes"] == s * 16 * tail_pad * 4
+    assert plan(16, 17 * P, [17 * P], bf)["splits"] == 1                                       # 2.875 rounds: nothing to gain
     p128 = plan(16, 128 * P, [128 * P], f16)
     assert (p128["q_tile"], p128["tail_q_tile"], p128["splits"]) == (256, 0, 1)               # f16: the lazy-rescale kernel, 256-row tiles
     # frame-local attention (S * 16 entries of 1374 rows): the tile that pads the sequence least once the launch is long enough

@@ -408,7 +408,8 @@ def test_full_depth_8_views_partial_aux_vs_oracle_model_forward():
     and the three heads -- on 8 views 518^2 with depth on views 2, 5 and cameras on views 0, 3, 7 (views with both, one, or no
     auxiliary modality) against oracle.model_forward (the bit-exact CPU restatement of omnivggt.py:20-68 /
     omnivggt_aggregator.py:130-256; ~2 min on the host cores). f32 and split-f16 modes: <= 1e-4 on the tokens of layers
-    0 / 4 / 11 / 17 / 23 and on pose / depth / points; bf16 (the timed mode): the twin-calibrated 3e-2 on tokens, finite predictions."""
+    0 / 4 / 11 / 17 / 23 and on pose / depth / points; bf16 (the timed mode): the twin-calibrated 3e-2 on tokens AND on every prediction
+    (round-5 review item 2; measured at 16 views: pose 8.4e-3, depth 5.9e-4, points 1.5e-2, confidences 3e-4)."""
     S, dgi, cgi = 8, [2, 5], [0, 3, 7]
     sd = common.full_state_dict()
     inp = orc.synthetic_inputs(S)
@@ -433,8 +434,42 @@ def test_full_depth_8_views_partial_aux_vs_oracle_model_forward():
             assert torch.isfinite(out[k]).all(), (dtype, k)
             errs[k] = common.max_rel(out[k].float().cpu(), rpred[k])
         print("8 views partial aux, full depth, %s vs oracle.model_forward: %s" % (repr(dtype).replace("torch.", ""), ", ".join("%s %.2e" % kv for kv in errs.items())))
-        gate = errs if dtype is not torch.bfloat16 else {k: v for k, v in errs.items() if k.startswith("tok_")}
-        assert max(gate.values()) <= tol, (dtype, errs)
+        assert max(errs.values()) <= tol, (dtype, errs)      # bf16: tokens AND predictions (pose / depth / points / confidences) <= 3e-2
+        del out, toks
+        torch.cuda.empty_cache()
+
+
+def test_full_depth_16_views_full_aux_vs_oracle_model_forward():
+    """Second full-depth BASELINE case, in the driver-run suite since round 6 (round-5 review item 2): configs[2] -- 16 views 518^2 with
+    depth AND camera on every view -- through the full model (24 + 24 + 24 blocks and the three heads) against oracle.model_forward
+    (omnivggt_aggregator.py:130-256, omnivggt.py:47-61; ~2 min incl. the oracle on the GPU box's host cores). f32 and split-f16 <= 1e-4
+    on the tokens of layers 0 / 4 / 11 / 17 / 23 and on pose / depth / points / confidences; bf16 <= 3e-2 on all of them
+    (measured: tokens 8.1e-3, pose 8.4e-3, depth 5.9e-4, points 1.5e-2)."""
+    S, dgi, cgi = 16, list(range(16)), list(range(16))
+    sd = common.full_state_dict()
+    inp = orc.synthetic_inputs(S)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(64, os.cpu_count()))
+    try:
+        with torch.no_grad():
+            ref = orc.model_forward(sd, inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
+    finally:
+        torch.set_num_threads(threads)
+    rtok = [ref["_tokens"][l][0, :, ::7, ::8] for l in common.TOK_LAYERS]
+    keys = ("pose_enc", "depth", "depth_conf", "world_points", "world_points_conf")
+    rpred = {k: ref[k] for k in keys}
+    del ref
+    m = build(sd, 24, 24, torch.float32)
+    for dtype, tol in ((torch.float32, F32_TOL), (L.F32X, F32_TOL), (torch.bfloat16, 3e-2)):
+        m.set_compute_dtype(dtype)
+        out = run_full(m, S, dgi, cgi)
+        toks, _ = run_agg(m, S, dgi, cgi)
+        errs = {"tok_L%d" % l: common.max_rel(toks[l][0, :, ::7, ::8].cpu(), r) for l, r in zip(common.TOK_LAYERS, rtok)}
+        for k in keys:
+            assert torch.isfinite(out[k]).all(), (dtype, k)
+            errs[k] = common.max_rel(out[k].float().cpu(), rpred[k])
+        print("16 views full aux, full depth, %s vs oracle.model_forward: %s" % (repr(dtype).replace("torch.", ""), ", ".join("%s %.2e" % kv for kv in errs.items())))
+        assert max(errs.values()) <= tol, (dtype, errs)
         del out, toks
         torch.cuda.empty_cache()
 
@@ -482,7 +517,7 @@ def test_batch_of_two_scenes_depth2(reduced, S, dgi, cgi):
 
 def test_batch_of_two_scenes_full_depth_model_forward():
     """B = 2 x S = 2 (depth on view 1, cameras on both) through the FULL model -- 24 + 24 + 24 blocks and the three heads -- against
-    oracle.model_forward (omnivggt.py:20-68): f32 and split-f16 <= 1e-4 on tokens and predictions, bf16 tokens <= 3e-2."""
+    oracle.model_forward (omnivggt.py:20-68): f32 and split-f16 <= 1e-4, bf16 <= 3e-2, on tokens and on every prediction."""
     B, S, dgi, cgi = 2, 2, [1], [0, 1]
     sd = common.full_state_dict()
     cpu = batch_inputs(B, S)
@@ -509,8 +544,7 @@ def test_batch_of_two_scenes_full_depth_model_forward():
             assert out[k].shape[0] == B and torch.isfinite(out[k]).all(), (dtype, k)
             errs[k] = max(common.max_rel(out[k][b].float().cpu(), rpred[k][b]) for b in range(B))
         print("B=2 S=2 full depth, %s vs oracle.model_forward: %s" % (repr(dtype).replace("torch.", ""), ", ".join("%s %.2e" % kv for kv in errs.items())))
-        gate = errs if dtype is not torch.bfloat16 else {k: v for k, v in errs.items() if k.startswith("tok_")}
-        assert max(gate.values()) <= tol, (dtype, errs)
+        assert max(errs.values()) <= tol, (dtype, errs)      # bf16: tokens AND predictions (pose / depth / points / confidences) <= 3e-2
         del out, toks
         torch.cuda.empty_cache()
 

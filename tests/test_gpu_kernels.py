@@ -68,20 +68,24 @@ def test_camera_head_entry_vs_twin_and_f32_module():
 
 
 def test_gemm256_kernels_every_epilogue_ragged_m():
-    """The 256 x 256 ping-pong GEMMs the 64-view bench runs (qkv256_kernel, linear256_kernel<GELU|RES|STORE|PATCH>)."""
+    """The 256 x 256 GEMMs the 64-view bench runs (qkv256_kernel, linear256_kernel<GELU|RES|STORE|PATCH>; free-running main loop since round 6)."""
     st.test_gemm256(False)
     _assert_clean()
 
 
 def test_history_variants_are_not_in_the_product_library():
-    """Round-4 review, hygiene: the A/B history (r02 epilogue forms, attention variants of rounds 1-3) and the round-5 lab GEMM forms are compiled
-    only into tools/probes/build_alt.py builds (-DOVG_AB_VARIANTS / -DOVG_LAB_GEMM); the product library refuses them by name."""
+    """Round-4 review, hygiene: the A/B history (r02 epilogue forms, attention variants of rounds 1-3) is compiled only into
+    tools/probes/build_alt.py builds (-DOVG_AB_VARIANTS); the product library refuses them by name. The round-5 lab GEMM selectors
+    (4 = persistent 256 x 256, 10 = DMA-in-M) left the ABI in round 6: they are plain argument errors now."""
     import torch
     from omnivggt_official_amd import ops
     x = torch.zeros(512, 1024, device="cuda", dtype=torch.bfloat16)
     w = torch.zeros(1024, 1024, device="cuda", dtype=torch.bfloat16)
-    for tile in (L.TILE_256X, L.TILE_128X, L.TILE_256P, L.TILE_256M):
+    for tile in (L.TILE_256X, L.TILE_128X):
         with pytest.raises(L.OvgError, match="UNSUPPORTED"):
+            ops.linear(x, w, None, torch.bfloat16, tile=tile)
+    for tile in (4, 10, 42):
+        with pytest.raises(L.OvgError, match="ARG"):
             ops.linear(x, w, None, torch.bfloat16, tile=tile)
     q, k, vt = ops.alloc_qkv(16, 256, 256, torch.bfloat16, "cuda")
     for variant in (6, 21, 33, 51, 59):

@@ -155,14 +155,20 @@ class FakeAgg:
         return self.grid_hw
 
 
-def _worker(rank, world, port, S, dgi, cgi, result_dir, hw=518, mode="auto"):
+def batch_inputs(B, S, hw):
+    """B different scenes stacked on the batch axis (as tests/test_gpu_aggregator.py batch_inputs)."""
+    parts = [orc.synthetic_inputs(S, seed=1234 + 1111 * b, hw=hw) for b in range(B)]
+    return {k: torch.cat([q[k] for q in parts], 0) for k in parts[0]}
+
+
+def _worker(rank, world, port, S, dgi, cgi, result_dir, hw=518, mode="auto", B=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 2) // world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         sd = common.reduced_state_dict(DEPTH, DINO)
-        inp = orc.synthetic_inputs(S, hw=hw)
+        inp = orc.synthetic_inputs(S, hw=hw) if B == 1 else batch_inputs(B, S, hw)
         sh = sharding.ViewSharding(executor_factory=lambda agg, dev: OracleExecutor(sd, DEPTH), gather_output=True,
                                    mode="auto" if mode == "choose" else ("heads" if mode == "heads_bad" else mode))
         fa = FakeAgg()
@@ -212,6 +218,29 @@ def test_view_sharded_forward_matches_monolithic_oracle(tmp_path, S, dgi, cgi, h
     for a, b in zip(sharded, ref):
         assert a.shape == b.shape == (1, S, P, 2048)
         assert common.max_rel(a, b) < 2e-5
+
+
+@pytest.mark.parametrize("S,dgi,cgi,mode", [(2, [1], [0, 1], "heads"), (3, [0, 2], [1], "allgather")])
+def test_view_sharded_batch_of_two_scenes(tmp_path, S, dgi, cgi, mode):
+    """Round-5 review item 5: (B, S, ...) batches on the sharded path (omnivggt.py:31-32; the single-GPU form is covered by
+    tests/test_gpu_aggregator.py test_batch_of_two_scenes_*). 2 ranks x B = 2 different scenes, even split through the head-parallel form
+    and an uneven split (3 views) through the K / V^T all-gather form, against the monolithic oracle on the same (2, S, ...) tensors:
+    per-entry depth statistics, per-entry camera frame, per-entry global sequence, shared index lists."""
+    world, hw, B = 2, (210, 266), 2
+    mp.spawn(_worker, args=(world, _free_port(), S, dgi, cgi, str(tmp_path), hw, mode, B), nprocs=world, join=True)
+    sharded = torch.load(os.path.join(str(tmp_path), "sharded.pt"))
+    sd = common.reduced_state_dict(DEPTH, DINO)
+    inp = batch_inputs(B, S, hw)
+    P = (hw[0] // 14) * (hw[1] // 14) + 5
+    with torch.no_grad():
+        ref, _ = orc.aggregator_forward(sd, inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi,
+                                        depth_layers=DEPTH, dino_layers=DINO)
+    assert len(sharded) == DEPTH
+    for a, b in zip(sharded, ref):
+        assert a.shape == b.shape == (B, S, P, 2048)
+        for e in range(B):
+            assert common.max_rel(a[e], b[e]) < 2e-5
+    assert common.max_rel(ref[-1][0], ref[-1][1]) > 1e-2          # the two entries ARE different scenes
 
 
 @pytest.mark.parametrize("world,S,dgi,cgi,mode", [(4, 8, [1, 6], [0, 5], "auto"), (4, 6, [5], [0, 3], "auto"),
