@@ -183,6 +183,8 @@ class BlockRunner:
             setattr(p, "ws_" + name, L.ptr(hi))
             setattr(p, "ws_%s_lo" % name, L.ptr(lo))
         p.attn_variant = int(getattr(self.knobs, "attn_variant", 0))
+        if L.is_split(self.dtype) and p.attn_variant == 0 and getattr(self.knobs, "f32x_exact_pv", False):
+            p.attn_variant = L.ATTN_F32X_EXACT_PV                # split-f16 mode with all three products of the PV contraction (rounds 4-5)
         p.gemm_tile = int(getattr(self.knobs, "gemm_tile", 0))
         p.attn_kv_splits = int(getattr(self.knobs, "attn_kv_splits", 0))
         p.attn_fallback_count = L.ptr(getattr(self.knobs, "fallback_counter", None))
@@ -250,6 +252,7 @@ class ZeroAggregator(nn.Module):
         self.attn_variant = 0       # ovg_attn_params.variant of every attention call (0 = library default); read per call
         self.gemm_tile = 0          # OVG_TILE_* forced on the block GEMMs (tests); 0 = shape heuristic
         self.attn_kv_splits = 0     # ovg_attn_params.kv_splits: 0 = library decides per launch, 1 = never split
+        self.f32x_exact_pv = False  # split-f16 mode: True = all three products of the attention's PV contraction (1.07e-5 of the f32 mode at 64 views, 28 frames/s); False (round 6) = without P_lo x V_hi (2.96e-5, 32.6 frames/s)
         self.attn_cus = 0           # ovg_attn_params.cus of the BlockRunner launches (0 = the whole device). The sharded run leaves it at 0: frame / DINOv2 attention never overlaps an exchange; the global-attention launches that DO take their budget from sharding.HipExecutor.cus
         self.max_workspaces = 4     # scratch shapes kept alive (frame + global of the two most recent geometries)
         self.shard = None           # set by sharding.ViewSharding for the multi-GPU path

@@ -20,8 +20,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", 
 EXTRA_FLAGS = {"ovg_attn.hip": ["-fno-honor-nans"]}
 
 
-# attn16_kernel<bf16, QB, WAVES, MODE 0, OCC 2, VSUM false, DMA, X3 false>: the three launches of the bf16 plan (mangled-name fragment -> QB)
-PINNED_ATTENTION_KERNELS = {"IDF16bLi4ELi8ELi0ELi2ELb0ELi5ELb0E": 4, "IDF16bLi4ELi4ELi0ELi2ELb0ELi3ELb0E": 4, "IDF16bLi2ELi4ELi0ELi2ELb0ELi3ELb0E": 2}
+# attn16_kernel<bf16, QB, WAVES, MODE 0, OCC 2, VSUM false, DMA, X3 0>: the three launches of the bf16 plan (mangled-name fragment -> QB)
+PINNED_ATTENTION_KERNELS = {"IDF16bLi4ELi8ELi0ELi2ELb0ELi5ELi0E": 4, "IDF16bLi4ELi4ELi0ELi2ELb0ELi3ELi0E": 4, "IDF16bLi2ELi4ELi0ELi2ELb0ELi3ELi0E": 2}
 
 
 # everything a pinned hot loop may contain besides scalar (s_*) instructions
@@ -78,6 +78,62 @@ def check_pinned_attention_loops(asm_text):
                                "trustworthy" % (pat, sorted(set(bad))))
         report[pat] = {"instructions": len(hot), "mfma": 18 * qb}
     return report
+
+TRANS_OPS = ("v_exp_f32", "v_log_f32", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32", "v_exp_f16", "v_log_f16", "v_rcp_f16", "v_rsq_f16", "v_sqrt_f16")
+
+
+def _vregs(operand):
+    """VGPR numbers named by one operand: v12, -v12, |v12|, v[4:7]."""
+    import re
+    out = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", operand):
+        out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bv(\d+)\b", operand):
+        out.add(int(m.group(1)))
+    return out
+
+
+def check_trans_use_in_asm(asm_text):
+    """gfx950: the result of a transcendental VALU instruction (v_exp_f32, v_rcp_f32, ...) may not be read by a VALU instruction in the next
+    issue slot. hipcc pads that for the instructions it schedules, NOT for an inline-asm statement that reads the register (it treats the
+    statement as opaque: cdna_hip_programming.md 5.7 item 2) -- the reader then sees the OLD register contents, silently. Round 6 found the
+    split-f16 attention body (v_exp_f32 by the compiler, v_cvt_pk_f16_f32 / v_fma_mix / v_pk_add_f32 in asm statements) depending on where the
+    scheduler happened to put its exps. This check walks the assembly of a translation unit and refuses any compiler-scheduled transcendental
+    whose destination is read by the inline-asm instruction that directly follows it. Returns the number of (transcendental, asm) neighbours seen."""
+    seen, in_asm, prev = 0, False, None          # prev = (mnemonic, dest regs) of the previous real instruction if the compiler scheduled it
+    for line in asm_text.splitlines():
+        t = line.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not line.startswith("\t") or not t or t.startswith((".", ";")):
+            if t.endswith(":"):
+                prev = None                      # a label: the fall-through neighbour is still the previous instruction, but be conservative
+            continue
+        mnem, _, rest = t.partition(" ")
+        ops = [o.strip() for o in rest.split(",")]
+        if in_asm and prev is not None and (mnem.startswith("v_") or mnem.startswith("ds_") or mnem.startswith("global_") or mnem.startswith("buffer_")):
+            seen += 1
+            srcs = set()
+            for o in (ops[1:] if mnem.startswith("v_") and not mnem.startswith("v_cmp") else ops):
+                srcs |= _vregs(o)
+            if mnem.startswith("v_fma_mix") or mnem.startswith("v_pk_add") or mnem.startswith("v_mfma"):
+                srcs |= _vregs(ops[0])           # read-modify-write destinations
+            if srcs & prev[1]:
+                raise RuntimeError("trans-use check: compiler-scheduled %s writes v%s and the inline-asm `%s` directly behind it reads it -- "
+                                   "hipcc pads no hazard for asm statements; put an opaque wait state between them (ovg_attn16.h pv_step)"
+                                   % (prev[0], sorted(prev[1]), t))
+        if mnem == "s_nop":
+            prev = None
+            continue
+        if not in_asm and mnem.split("_e32")[0].split("_e64")[0] in TRANS_OPS:
+            prev = (mnem, _vregs(ops[0]))
+        else:
+            prev = None
+    return seen
 
 
 def _hipcc():
@@ -148,7 +204,9 @@ def build(force=False, verbose=True):
                     if len(asm) != 1:
                         raise RuntimeError("pinned-attention check: expected one gfx950 assembly file of ovg_attn.hip, found %r" % asm)
                     try:
-                        check_pinned_attention_loops(open(os.path.join(objdir, asm[0])).read())
+                        text = open(os.path.join(objdir, asm[0])).read()
+                        check_pinned_attention_loops(text)
+                        check_trans_use_in_asm(text)
                     except RuntimeError as e:
                         # a hipcc that schedules the pinned body differently must not leave the user without a library (round-5 advisor):
                         # the compiler-scheduled body is the same arithmetic without hand-placed instructions -- nothing for the guard to

@@ -451,7 +451,7 @@ int64_t split_part_rows(const ovg_attn_params& p, int bq, int64_t row0, int64_t 
   return row0 == 0 ? p.nq_pad : (row1 - row0 + bq - 1) / bq * bq;
 }
 
-template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false, int DMA = 0, bool X3 = false>
+template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false, int DMA = 0, int X3 = 0>
 int launch_attn16(const ovg_attn_params& p, const Plan16& pl, hipStream_t st, int64_t row0 = 0, int64_t row1 = -1) {   // q rows [row0, row1) (default: all)
   constexpr int BQ = 16 * QB * WAVES;
   if (row1 < 0) row1 = p.nq;
@@ -555,7 +555,9 @@ int dispatch_x3(const ovg_attn_params& p, hipStream_t st) {
   Plan16 pl{};
   pl.variant = 90; pl.bq = 256; pl.splits = 1; pl.total_tiles = total_key_tiles(p); pl.per_split = pl.total_tiles;
   pl.main_rows = p.nq; pl.tail_bq = 0; pl.tail_splits = 0;
-  return launch_attn16<f16_t, 2, 8, 1, 2, true, OVG_ATTN_X3_RING, true>(p, pl, st);
+  // variant 93 (OVG_ATTN_F32X_EXACT_PV): all three products of the PV contraction (rounds 4-5); default: two (ovg_attn16.h, pv_step)
+  if (p.variant == 93) return launch_attn16<f16_t, 2, 8, 1, 2, true, OVG_ATTN_X3_RING, 3>(p, pl, st);
+  return launch_attn16<f16_t, 2, 8, 1, 2, true, OVG_ATTN_X3_RING, 2>(p, pl, st);
 }
 
 }  // namespace

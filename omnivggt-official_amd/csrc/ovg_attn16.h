@@ -105,6 +105,10 @@ OVG_DEV u32x4 pack2(const f32x4 a, const f32x4 b) {
 #ifndef OVG_ATTN_X3_SPLIT
 #define OVG_ATTN_X3_SPLIT 1
 #endif
+// Products of the PV contraction of the split-f16 mode (template value X3 of the kernels; round 6, profiles/r06_f32x_pv_terms_ab.txt): 3 = P_hi V_lo
+// + P_lo V_hi + P_hi V_hi (rounds 4-5; 1.07e-5 of the f32 mode at layer 23 of 64 views, 28.1 frames/s); 2 = without P_lo V_hi (2.96e-5, 32.6 frames/s:
+// the default since round 6, ovg_attn_params.variant 93 selects 3); P_hi V_hi alone measured 4.6e-5 / 35.2 frames/s and is not offered.
+template <bool WANT_LO = true>
 OVG_DEV void pack2_hilo(const f32x4 a, const f32x4 b, u32x4& hi, u32x4& lo) {
 #if OVG_ATTN_X3_SPLIT
   const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -117,6 +121,11 @@ OVG_DEV void pack2_hilo(const f32x4 a, const f32x4 b, u32x4& hi, u32x4& lo) {
   }
   hi = u32x4{h[0], h[1], h[2], h[3]};
   lo = u32x4{l[0], l[1], l[2], l[3]};
+  // hipcc pads nothing for inline asm (cdna_hip_programming.md 5.7 item 2): a VGPR written by the statements above must not feed an MFMA in
+  // the next two issue slots. Rounds 4-5 relied on the fragment reads that happened to sit in between; this statement makes it a property of
+  // the code (found in round 6: with the P_lo product removed in a lab build the convert landed directly in front of its MFMA -- garbage).
+  if constexpr (WANT_LO) asm volatile("s_nop 1" : "+v"(hi), "+v"(lo));
+  else asm volatile("s_nop 1" : "+v"(hi));
 #else
   f16_t h[8], l[8];
 #pragma unroll
@@ -162,7 +171,7 @@ OVG_DEV void rowsum_acc(f32x4& lacc, const f32x4 sa, const f32x4 sb) {
 // -0.6 ... -1.2 %, and a loop that issues QK^T of tile j + 1 inside the exp / split block of tile j (4-slot ring, 191 VGPRs, no spill,
 // MFMA / VALU interleaved by hipcc as intended) -2.2 ... -2.6 % -- the kernel issues 1400 TFLOP/s of f16 MFMAs, the same rate as the bf16
 // kernel with its row-sum MFMAs: neither VALU issue nor phase alignment of the two waves of a SIMD is what holds it there (section 5.1).
-template <typename T, int QB, int WAVES, int SM, bool VSUM = false, int DMA = 0, bool X3 = false>   // VSUM: row sums on the VALU (experiment, variant 31) instead of the ones-MFMA; DMA: 0 = register staging, R = 2 B + 1 (3, 5, 7, 9): K / V^T tiles by LDS-DMA into a ring of R slots, B + 1 tiles ahead, one workgroup barrier every B tiles
+template <typename T, int QB, int WAVES, int SM, bool VSUM = false, int DMA = 0, int X3 = 0>   // VSUM: row sums on the VALU (experiment, variant 31) instead of the ones-MFMA; DMA: 0 = register staging, R = 2 B + 1 (3, 5, 7, 9): K / V^T tiles by LDS-DMA into a ring of R slots, B + 1 tiles ahead, one workgroup barrier every B tiles
 OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int bh, const int q0, const int t_begin, const int total_tiles,
                        f32x4 (&o)[QB][4], f32x4 (&lacc)[QB], f32x4 (&negm)[QB]) {   // key tiles [t_begin, t_begin + total_tiles) of the flattened segment list
   constexpr int NT = 64 * WAVES;
@@ -375,8 +384,15 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
       u32x4 ph[QB], pl[QB];
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
-        pack2_hilo(sa[qb], sb[qb], ph[qb], pl[qb]);
-        rowsum_acc(lacc[qb], sa[qb], sb[qb]);         // exact f32 row sums, lane-partial, reduced once after the loop
+        // The P values come out of v_exp_f32 (a transcendental: its result may not be read by a VALU instruction in the next issue slot) and
+        // go into INLINE-ASM VALU statements (pack2_hilo, rowsum_acc), which hipcc does not pad (cdna_hip_programming.md 5.7 item 2): whether
+        // an exp landed directly in front of its asm reader was up to the scheduler. Rounds 4-5 passed their 1e-5 checks with the schedule they
+        // happened to get; in round 6 an unrelated edit moved one exp and the split-f16 attention dropped to f16-level errors (1e-3). One opaque
+        // wait state between the exps and every asm reader makes it a property of the code.
+        f32x4 pa = sa[qb], pb = sb[qb];
+        asm volatile("s_nop 0" : "+v"(pa), "+v"(pb));
+        pack2_hilo<(X3 >= 3)>(pa, pb, ph[qb], pl[qb]);
+        rowsum_acc(lacc[qb], pa, pb);                 // exact f32 row sums, lane-partial, reduced once after the loop
       }
       const int voff = ((4 * u + g) ^ sx) << 4;
 #pragma unroll
@@ -385,8 +401,10 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
         const u32x4 vfl = *reinterpret_cast<const u32x4*>(vl + PLANE_B + dt * 2048 + frag_row + voff);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
+          // X3 = 3: P_hi V_lo + P_lo V_hi + P_hi V_hi; X3 = 2 (the default of the mode since round 6): without P_lo V_hi -- P is then an 11-bit
+          // f16 value per key, V stays (hi, lo), the row sums stay exact f32
           o[qb][dt] = mma_c<T>(vfl, ph[qb], o[qb][dt]);
-          o[qb][dt] = mma_c<T>(vf, pl[qb], o[qb][dt]);
+          if constexpr (X3 >= 3) o[qb][dt] = mma_c<T>(vf, pl[qb], o[qb][dt]);
           o[qb][dt] = mma_c<T>(vf, ph[qb], o[qb][dt]);
         }
       }
@@ -577,7 +595,7 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
 // or, in a split-KV pass, the head-major partial [split][entry][part_rows][64] (f32 since round 5: the bf16 partials of rounds 2-4 were an
 // extra rounding point, 6.9e-3 between a split and an unsplit launch of the same call; now ~1e-6 before the final rounding) with its
 // log-sum-exp. Partial rows are relative to q_row0, the first row of the launch (the key-split tail launch covers rows [q_row0, nq) only).
-template <typename T, int QB, bool X3 = false>
+template <typename T, int QB, int X3 = 0>
 OVG_DEV void write_out(const ovg_attn_params& p, const f32x4 (&o)[QB][4], const f32x4 (&lacc)[QB], const f32x4 (&negm)[QB],
                        const int bh, const int q0, const int sp, const int splits, const int q_row0 = 0, const int part_rows = 0) {
   const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
@@ -612,7 +630,7 @@ OVG_DEV void write_out(const ovg_attn_params& p, const f32x4 (&o)[QB][4], const 
 }  // namespace attn16
 
 // MODE: 0 = speculative anchored softmax + verified fallback, 1 = lazy-rescale only, 2 = forced fallback (tests)
-template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false, int DMA = 0, bool X3 = false>   // OCC: minimum waves per SIMD the register allocation must allow; X3: split-f16 planes (run_tiles)
+template <typename T, int QB, int WAVES, int MODE, int OCC = 2, bool VSUM = false, int DMA = 0, int X3 = 0>   // OCC: minimum waves per SIMD the register allocation must allow; X3: split-f16 planes (run_tiles)
 __global__ __launch_bounds__(64 * WAVES, OCC) void attn16_kernel(ovg_attn_params p, int nqt, int total_tiles, int splits, int per_split, int q_row0, int part_rows) {   // q tiles [0, nqt) of the rows starting at q_row0; part_rows: rows per entry of the split workspace
   static_assert(sizeof(T) == 2, "16-bit types only");
   constexpr int RB = 128, KT_B = BC * RB, VT_B = OVG_D * RB, BQ = 16 * QB * WAVES;

@@ -218,9 +218,10 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ovg_conv_params p, int OH,
 
 #include "ovg_conv256.h"
 
-// 256 x 256 form (16-bit modes, GEMM columns a multiple of 256, two images within 32-bit byte offsets): ovg_conv256.h
-template <typename T>
-__global__ __launch_bounds__(512) void conv256_kernel(ovg_conv_params p, int OH, int OW, int M, int ntiles_n) {
+// 256-pixel tiles on the LDS-DMA ring (16-bit modes, two images within 32-bit byte offsets; ovg_conv256.h): WN = 4 -- 256 GEMM columns per tile,
+// 8 waves, one workgroup per CU; WN = 2 -- 128 columns per tile, 4 waves, two workgroups per CU (output_conv1: 128 output channels)
+template <typename T, int WN>
+__global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void conv256_kernel(ovg_conv_params p, int OH, int OW, int M, int ntiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_c256[];
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int mtiles = (M + 255) / 256;
@@ -229,11 +230,11 @@ __global__ __launch_bounds__(512) void conv256_kernel(ovg_conv_params p, int OH,
   const int m_first = grp * 4;
   const int gsz = (mtiles - m_first) < 4 ? (mtiles - m_first) : 4;
   const int tm = m_first + rem % gsz, tn = rem / gsz;
-  const int m0 = tm * 256, n0 = tn * 256;
+  const int m0 = tm * 256, n0 = tn * c256::Geo<WN>::BN;
   f32x4 acc[4][8];
-  c256::mainloop<T>(p, M, OH, OW, m0, n0, lds_c256, acc);
+  c256::mainloop<T, WN>(p, M, OH, OW, m0, n0, lds_c256, acc);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  conv_epilogue<T, false, 8>(p, acc, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, OH, OW, M);
+  conv_epilogue<T, false, 8>(p, acc, m0 + (wave / WN) * 128, n0 + (wave & (WN - 1)) * 64, OH, OW, M);
 }
 
 // ---------------------------------------------------------------------------
@@ -375,27 +376,35 @@ extern "C" int ovg_conv(const ovg_conv_params* p, void* stream) {
   const int M = (int)M64, nt = p->w_rows / 128;
   const dim3 grid((unsigned)(((M + 127) / 128) * nt)), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // 256 x 256 LDS-DMA form (ovg_conv256.h): 16-bit, 16-bit output, every GEMM column real (w_rows == the GEMM's columns, a multiple of 256),
-  // 32-channel k-stages, enough pixels for at least one round of the chip, and two images within the 32-bit byte offsets of its descriptor
+  // 256-pixel LDS-DMA forms (ovg_conv256.h): 16-bit, 16-bit output, every GEMM column real (w_rows == the GEMM's columns), 32-channel k-stages in
+  // pairs (the free-running loop walks two k-stages per iteration), enough pixels for at least one round of the chip, and two images within
+  // the 32-bit byte offsets of its descriptor. 256-column tiles where the columns allow, else 128-column tiles at two workgroups per CU.
   const int64_t two_images = 2 * (int64_t)p->H * p->W * p->ldx * 2;
   const int gemm_cols = s * s * p->Cout;
-  if (p->dtype != OVG_F32 && !p->out_f32 && p->w_rows == gemm_cols && gemm_cols % 256 == 0 && p->Cin % 32 == 0 && M >= 16384 &&
-      two_images < ((int64_t)1 << 32) - 65536 && (int64_t)p->w_rows * p->ksize * p->ksize * p->Cin * 2 < ((int64_t)1 << 32)) {
-    const int nt2 = p->w_rows / 256;
+  if (p->dtype != OVG_F32 && !p->out_f32 && p->w_rows == gemm_cols && gemm_cols % 128 == 0 && p->Cin % 32 == 0 && (p->ksize * p->ksize * (p->Cin / 32)) % 2 == 0 &&
+      M >= 16384 && two_images < ((int64_t)1 << 32) - 65536 && (int64_t)p->w_rows * p->ksize * p->ksize * p->Cin * 2 < ((int64_t)1 << 32)) {
+    const bool wide = gemm_cols % 256 == 0;
+    const int nt2 = p->w_rows / (wide ? 256 : 128);
     const dim3 grid2((unsigned)(((M + 255) / 256) * nt2));
     // > 64 KB of dynamic LDS is a per-device opt-in of the kernel: done once per (kernel, device), remembered in a bit mask (idempotent; a
     // race between two threads sets it twice)
-    static unsigned opted[2] = {0u, 0u};
+    static unsigned opted[4] = {0u, 0u, 0u, 0u};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return OVG_E_LAUNCH;
-    const int which = p->dtype == OVG_BF16 ? 0 : 1;
+    const int which = (p->dtype == OVG_BF16 ? 0 : 1) + (wide ? 0 : 2);
+    const int lds_b = wide ? c256::Geo<4>::LDS_BYTES : c256::Geo<2>::LDS_BYTES;
     if (dev >= 32 || !((opted[which] >> dev) & 1u)) {
-      const void* fn = which == 0 ? reinterpret_cast<const void*>(conv256_kernel<bf16_t>) : reinterpret_cast<const void*>(conv256_kernel<f16_t>);
-      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, c256::LDS_BYTES) != hipSuccess) return OVG_E_LAUNCH;
+      const void* fn = which == 0 ? reinterpret_cast<const void*>(conv256_kernel<bf16_t, 4>) : (which == 1 ? reinterpret_cast<const void*>(conv256_kernel<f16_t, 4>)
+                       : (which == 2 ? reinterpret_cast<const void*>(conv256_kernel<bf16_t, 2>) : reinterpret_cast<const void*>(conv256_kernel<f16_t, 2>)));
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b) != hipSuccess) return OVG_E_LAUNCH;
       if (dev < 32) opted[which] |= 1u << dev;
     }
-    if (which == 0) OVG_LAUNCH((conv256_kernel<bf16_t>), grid2, dim3(512), c256::LDS_BYTES, st, *p, OH, OW, M, nt2);
-    else OVG_LAUNCH((conv256_kernel<f16_t>), grid2, dim3(512), c256::LDS_BYTES, st, *p, OH, OW, M, nt2);
+    switch (which) {
+      case 0: OVG_LAUNCH((conv256_kernel<bf16_t, 4>), grid2, dim3(512), lds_b, st, *p, OH, OW, M, nt2); break;
+      case 1: OVG_LAUNCH((conv256_kernel<f16_t, 4>), grid2, dim3(512), lds_b, st, *p, OH, OW, M, nt2); break;
+      case 2: OVG_LAUNCH((conv256_kernel<bf16_t, 2>), grid2, dim3(256), lds_b, st, *p, OH, OW, M, nt2); break;
+      default: OVG_LAUNCH((conv256_kernel<f16_t, 2>), grid2, dim3(256), lds_b, st, *p, OH, OW, M, nt2); break;
+    }
     OVG_CHECK_LAUNCH();
     return OVG_OK;
   }

@@ -88,6 +88,20 @@ def gemm(args):
         x = torch.randn(M, K, generator=g).to(dt).to(DEV)
         w = (torch.randn(N, K, generator=g) * 0.03).to(dt).to(DEV)
         b = torch.randn(N, generator=g).to(DEV)
+        if args.rotate > 1:
+            # in the forward a block's weights are touched once per forward (1.9 GB of bf16 weights cycle through the caches): time the GEMM on
+            # `rotate` copies of W in turn, so that every launch streams its weights from HBM like the in-situ launch does
+            ws = [w] + [w.clone() for _ in range(args.rotate - 1)]
+            turn = [0]
+
+            class _Rot:
+                def data_ptr(self_inner):
+                    turn[0] = (turn[0] + 1) % len(ws)
+                    return ws[turn[0]].data_ptr()
+
+                def __getattr__(self_inner, k):
+                    return getattr(ws[0], k)
+            w = _Rot()
         if epi == "qkv":
             q, k, vt = ops.alloc_qkv(16, M, M, dt, DEV)
             qn = [torch.ones(64, device=DEV), torch.zeros(64, device=DEV), torch.ones(64, device=DEV), torch.zeros(64, device=DEV)]
@@ -138,6 +152,7 @@ def main():
     ap.add_argument("--square", type=int, nargs="*", default=[], help="GEMM: also time n^3 STORE problems (e.g. 4096 8192)")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--target-ms", type=float, default=20.0)
+    ap.add_argument("--rotate", type=int, default=1, help="GEMM: cycle over this many copies of the weight matrix (weights from HBM, as in the forward)")
     ap.add_argument("--out", default="")
     ap.add_argument("--alt-lib", default="", help="name of an alternate build under tools/probes/_build/ (build_alt.py) to run on instead of the product library")
     args = ap.parse_args()
