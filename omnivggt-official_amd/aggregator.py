@@ -183,8 +183,8 @@ class BlockRunner:
             setattr(p, "ws_" + name, L.ptr(hi))
             setattr(p, "ws_%s_lo" % name, L.ptr(lo))
         p.attn_variant = int(getattr(self.knobs, "attn_variant", 0))
-        if L.is_split(self.dtype) and p.attn_variant == 0 and getattr(self.knobs, "f32x_exact_pv", False):
-            p.attn_variant = L.ATTN_F32X_EXACT_PV                # split-f16 mode with all three products of the PV contraction (rounds 4-5)
+        if L.is_split(self.dtype) and p.attn_variant == 0 and getattr(self.knobs, "f32x_fast_pv", False):
+            p.attn_variant = L.ATTN_F32X_FAST_PV                 # split-f16 mode without the P_lo x V_hi product of the PV contraction (opt-in)
         p.gemm_tile = int(getattr(self.knobs, "gemm_tile", 0))
         p.attn_kv_splits = int(getattr(self.knobs, "attn_kv_splits", 0))
         p.attn_fallback_count = L.ptr(getattr(self.knobs, "fallback_counter", None))
@@ -252,9 +252,10 @@ class ZeroAggregator(nn.Module):
         self.attn_variant = 0       # ovg_attn_params.variant of every attention call (0 = library default); read per call
         self.gemm_tile = 0          # OVG_TILE_* forced on the block GEMMs (tests); 0 = shape heuristic
         self.attn_kv_splits = 0     # ovg_attn_params.kv_splits: 0 = library decides per launch, 1 = never split
-        self.f32x_exact_pv = False  # split-f16 mode: True = all three products of the attention's PV contraction (1.07e-5 of the f32 mode at 64 views, 28 frames/s); False (round 6) = without P_lo x V_hi (2.96e-5, 32.6 frames/s)
+        self.f32x_fast_pv = False   # split-f16 mode, opt-in (round 6): True = attention's PV contraction without P_lo x V_hi: +16 % (64 views 28.1 -> 32.6 frames/s) at 3e-5 of the f32 mode at full depth but up to 1.0e-4 on single rows (64-view depth-1 camera token) -- outside the mode's <= 1e-4 contract
         self.attn_cus = 0           # ovg_attn_params.cus of the BlockRunner launches (0 = the whole device). The sharded run leaves it at 0: frame / DINOv2 attention never overlaps an exchange; the global-attention launches that DO take their budget from sharding.HipExecutor.cus
         self.max_workspaces = 4     # scratch shapes kept alive (frame + global of the two most recent geometries)
+        self.layer_hook = None      # callable(layer index, outs[layer]) invoked after every global block of the single-GPU forward (OmniVGGT.forward: early DPT pyramid levels)
         self.shard = None           # set by sharding.ViewSharding for the multi-GPU path
         self.fallback_counter = None    # enable_fallback_counter(): device int32 the attention launches count their re-run workgroups into
         self._packed = None
@@ -562,4 +563,6 @@ class ZeroAggregator(nn.Module):
                 pk["frame"][i].forward(ws_f, x, buf[:, :C], inject=tables[i + 1], inj_period=P, **geo)
                 pk["global"][i].forward(ws_g, buf[:, :C], buf[:, C:], events=self.next_attention_events(4.0 * B * (S * P) ** 2 * C), **geo)
                 x = buf[:, C:]
+                if self.layer_hook is not None:
+                    self.layer_hook(i, outs[i])                  # outs[i] is final (queued on the current stream): OmniVGGT starts the DPT pyramid levels of layers 4 / 11 / 17 here
         return outs, self.patch_start_idx

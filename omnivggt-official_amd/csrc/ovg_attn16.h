@@ -106,8 +106,9 @@ OVG_DEV u32x4 pack2(const f32x4 a, const f32x4 b) {
 #define OVG_ATTN_X3_SPLIT 1
 #endif
 // Products of the PV contraction of the split-f16 mode (template value X3 of the kernels; round 6, profiles/r06_f32x_pv_terms_ab.txt): 3 = P_hi V_lo
-// + P_lo V_hi + P_hi V_hi (rounds 4-5; 1.07e-5 of the f32 mode at layer 23 of 64 views, 28.1 frames/s); 2 = without P_lo V_hi (2.96e-5, 32.6 frames/s:
-// the default since round 6, ovg_attn_params.variant 93 selects 3); P_hi V_hi alone measured 4.6e-5 / 35.2 frames/s and is not offered.
+// + P_lo V_hi + P_hi V_hi (the mode: 1.07e-5 of the f32 mode at layer 23 of 64 views, 28.1 frames/s); 2 = without P_lo V_hi (2.96e-5 there and
+// 32.6 frames/s, but 1.0e-4 on the camera token of the 64-view depth-1 parity case: opt-in through ovg_attn_params.variant 92, outside the
+// <= 1e-4 contract); P_hi V_hi alone measured 4.6e-5 / 35.2 frames/s and is not offered.
 template <bool WANT_LO = true>
 OVG_DEV void pack2_hilo(const f32x4 a, const f32x4 b, u32x4& hi, u32x4& lo) {
 #if OVG_ATTN_X3_SPLIT
@@ -401,8 +402,8 @@ OVG_DEV void run_tiles(const ovg_attn_params& p, unsigned char* lds, const int b
         const u32x4 vfl = *reinterpret_cast<const u32x4*>(vl + PLANE_B + dt * 2048 + frag_row + voff);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-          // X3 = 3: P_hi V_lo + P_lo V_hi + P_hi V_hi; X3 = 2 (the default of the mode since round 6): without P_lo V_hi -- P is then an 11-bit
-          // f16 value per key, V stays (hi, lo), the row sums stay exact f32
+          // X3 = 3: P_hi V_lo + P_lo V_hi + P_hi V_hi; X3 = 2 (opt-in, variant 92): without P_lo V_hi -- P is then an 11-bit f16 value per
+          // key, V stays (hi, lo), the row sums stay exact f32
           o[qb][dt] = mma_c<T>(vfl, ph[qb], o[qb][dt]);
           if constexpr (X3 >= 3) o[qb][dt] = mma_c<T>(vf, pl[qb], o[qb][dt]);
           o[qb][dt] = mma_c<T>(vf, ph[qb], o[qb][dt]);

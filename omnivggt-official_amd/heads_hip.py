@@ -99,50 +99,71 @@ class HipDPTHead:
         return self._pos[key]
 
     # -- forward ---------------------------------------------------------------------------------
-    def __call__(self, aggregated_tokens_list, images, patch_start_idx, frames_chunk_size=8, dtype=torch.bfloat16):
+    def __call__(self, aggregated_tokens_list, images, patch_start_idx, frames_chunk_size=8, dtype=torch.bfloat16, early=None):
+        """early: an EarlyLevels object of THIS head (begin_early) that was fed the intermediate layers while the aggregator was still running;
+        its pyramid levels are used instead of recomputing them (same kernels on the same data: bit-identical)."""
         B, S, _, H, W = images.shape
         step = S if (not frames_chunk_size or frames_chunk_size >= S) else frames_chunk_size
         vals, confs = [], []
         for b in range(B):
             pv, pc = [], []
             for s0 in range(0, S, step):
-                v, c = self._chunk(aggregated_tokens_list, b, s0, min(s0 + step, S), H, W, patch_start_idx, dtype)
+                pre = early.levels(b) if (early is not None and step == S and early.matches(B, S, H, W, dtype)) else None
+                v, c = self._chunk(aggregated_tokens_list, b, s0, min(s0 + step, S), H, W, patch_start_idx, dtype, pre=pre)
                 pv.append(v)
                 pc.append(c)
             vals.append(torch.cat(pv, 0) if len(pv) > 1 else pv[0])
             confs.append(torch.cat(pc, 0) if len(pc) > 1 else pc[0])
         return torch.stack(vals, 0), torch.stack(confs, 0)
 
-    def _rcu(self, w, x, dtype, add2=None, relu_out=False):
-        """ResidualConvUnit on an already ReLU'd input x: conv2(relu(conv1(x))) + x (+ add2) (ReLU'd if relu_out)."""
+    def begin_early(self, B, S, H, W, patch_start_idx, dtype):
+        """Start a forward whose pyramid levels are computed AS SOON AS their aggregator layer exists (OmniVGGT.forward feeds layers 4 / 11 / 17
+        from a hook on this head's side stream while the aggregator runs layers 5 .. 23): dpt_head.py:185-226 needs nothing but that layer."""
+        return EarlyLevels(self, B, S, H, W, patch_start_idx, dtype)
+
+    def _rcu(self, w, x, dtype, add2=None, relu_out=False, first=None):
+        """ResidualConvUnit on an already ReLU'd input x: conv2(relu(conv1(x))) + x (+ add2) (ReLU'd if relu_out).
+        first: relu(conv1(x)) if it was computed ahead (EarlyLevels)."""
         w1, b1, w2, b2 = w
-        t = ops.conv(x, w1, b1, dtype, 256, ksize=3, relu=True)
+        t = first if first is not None else ops.conv(x, w1, b1, dtype, 256, ksize=3, relu=True)
         return ops.conv(t, w2, b2, dtype, 256, ksize=3, add1=x, add2=add2, relu=relu_out)
 
-    def _chunk(self, toks, b, s0, s1, H, W, start, dtype):
+    def _level(self, P, i, t, n, H, W, start, dtype):
+        """Pyramid level i (dpt_head.py:185-226: norm -> projects[i] + position embedding -> resize_layers[i] -> layer{i+1}_rn, ReLU'd for its
+        consumers) from that layer's tokens t [n, tokens, 2C] f32."""
+        head = self.head
+        ps = head.patch_size
+        ph, pw = H // ps, W // ps
+        dev = t.device
+        oc = [m.weight.shape[0] for m in head.projects]
+        tpv = t.shape[1]
+        x = ops.head_layernorm(t.reshape(n * tpv, t.shape[2]), P["norm_w"], P["norm_b"], head.norm.eps, dtype, n,
+                               tokens_per_view=tpv, n_special=start)
+        x = x.view(n, ph, pw, -1)
+        w, bias = P["proj"][i]
+        x = ops.conv(x, w, bias, dtype, oc[i], ksize=1, pos=self._postab(oc[i], ph, pw, W, H, dev))
+        if i == 0:
+            x = ops.conv(x, P["up0"][0], P["up0"][1], dtype, oc[0], ksize=1, upshuffle=4)
+        elif i == 1:
+            x = ops.conv(x, P["up1"][0], P["up1"][1], dtype, oc[1], ksize=1, upshuffle=2)
+        elif i == 3:
+            x = ops.conv(x, P["down3"][0], P["down3"][1], dtype, oc[3], ksize=3, stride=2)
+        # layerN_rn (no bias); its only consumers open with the in-place ReLU -> emit relu(x)
+        return ops.conv(x, P["rn"][i], None, dtype, 256, ksize=3, relu=True)
+
+    def _chunk(self, toks, b, s0, s1, H, W, start, dtype, pre=None):
         head = self.head
         n, ps = s1 - s0, head.patch_size
         ph, pw = H // ps, W // ps
         dev = toks[0].device
         P = self._weights(dtype, dev)
-        oc = [m.weight.shape[0] for m in head.projects]
-        pyramid = []
+        pyramid, first = [], {}
         for i, layer in enumerate(head.intermediate_layer_idx):
-            t = toks[layer][b, s0:s1]                                   # [n, tokens, 2C] f32 view
-            tpv = t.shape[1]
-            x = ops.head_layernorm(t.reshape(n * tpv, t.shape[2]), P["norm_w"], P["norm_b"], head.norm.eps, dtype, n,
-                                   tokens_per_view=tpv, n_special=start)
-            x = x.view(n, ph, pw, -1)
-            w, bias = P["proj"][i]
-            x = ops.conv(x, w, bias, dtype, oc[i], ksize=1, pos=self._postab(oc[i], ph, pw, W, H, dev))
-            if i == 0:
-                x = ops.conv(x, P["up0"][0], P["up0"][1], dtype, oc[0], ksize=1, upshuffle=4)
-            elif i == 1:
-                x = ops.conv(x, P["up1"][0], P["up1"][1], dtype, oc[1], ksize=1, upshuffle=2)
-            elif i == 3:
-                x = ops.conv(x, P["down3"][0], P["down3"][1], dtype, oc[3], ksize=3, stride=2)
-            # layerN_rn (no bias); its only consumers open with the in-place ReLU -> emit relu(x)
-            pyramid.append(ops.conv(x, P["rn"][i], None, dtype, 256, ksize=3, relu=True))
+            if pre is not None and i in pre:
+                pyramid.append(pre[i][0])
+                first[i] = pre[i][1]
+                continue
+            pyramid.append(self._level(P, i, toks[layer][b, s0:s1], n, H, W, start, dtype))
 
         F = P["fusion"]
         # refinenet4: no skip
@@ -151,7 +172,7 @@ class HipDPTHead:
         y = ops.upsample(u, pyramid[2].shape[1], pyramid[2].shape[2], dtype)
         for lvl, skip, size in ((3, pyramid[2], pyramid[1].shape[1:3]), (2, pyramid[1], pyramid[0].shape[1:3]),
                                 (1, pyramid[0], (2 * pyramid[0].shape[1], 2 * pyramid[0].shape[2]))):
-            xs = self._rcu(F[lvl]["rcu1"], skip, dtype, add2=y, relu_out=True)      # relu(y + RCU1(skip))
+            xs = self._rcu(F[lvl]["rcu1"], skip, dtype, add2=y, relu_out=True, first=first.get(lvl - 1))      # relu(y + RCU1(skip))
             u = self._rcu(F[lvl]["rcu2"], xs, dtype)
             u = ops.conv(u, F[lvl]["out"][0], F[lvl]["out"][1], dtype, 256, ksize=1)
             y = ops.upsample(u, size[0], size[1], dtype)
@@ -163,6 +184,42 @@ class HipDPTHead:
         y = ops.upsample(y, ph * ps, pw * ps, dtype, pos=pos)
         hmap = ops.conv(y, P["oc2a"][0], P["oc2a"][1], dtype, 32, ksize=3, relu=True, out_f32=True)
         return ops.dpt_out(hmap, P["oc2b"][0], P["oc2b"][1], head.activation)
+
+
+class EarlyLevels:
+    """Pyramid levels of one HipDPTHead forward that were computed ahead of the head's own call (round 6). Level i of the DPT pyramid reads
+    ONE aggregator layer (intermediate_layer_idx[i] = 4 / 11 / 17 / 23): levels 0-2 -- LayerNorm, the 1x1 projection, the resize convolution,
+    layer{i+1}_rn and the first convolution of the fusion block's ResidualConvUnit on that skip -- are independent of everything the aggregator
+    computes after that layer. OmniVGGT.forward feeds them from a per-layer hook on the head's side stream, so ~40 % of a head's launches run
+    in the shadow of aggregator blocks 5 .. 23 (their partially filled last rounds leave CUs idle) instead of behind the last block.
+    The kernels, their inputs and their order per level are those of HipDPTHead._chunk: the results are bit-identical."""
+
+    def __init__(self, hip_head, B, S, H, W, patch_start_idx, dtype):
+        self.h, self.key, self.start, self.dtype = hip_head, (B, S, H, W, dtype), patch_start_idx, dtype
+        self.layers = list(hip_head.head.intermediate_layer_idx)
+        self._lv = {}                               # (b, i) -> (relu(layer_rn(...)), relu(conv1 of rcu1 on it))
+
+    def wants(self, layer_index):
+        """True when aggregator layer `layer_index` feeds one of the three early pyramid levels (never the last one: its layer ends the aggregator)."""
+        return layer_index in self.layers[:3] and layer_index != self.layers[3]
+
+    def feed(self, layer_index, tokens):
+        """tokens [B, S, P, 2C] f32 of aggregator layer `layer_index` (complete on the current stream)."""
+        B, S, H, W, dtype = self.key
+        P = self.h._weights(dtype, tokens.device)
+        for i, layer in enumerate(self.layers[:3]):
+            if layer != layer_index:
+                continue
+            for b in range(B):
+                pyr = self.h._level(P, i, tokens[b], S, H, W, self.start, dtype)
+                w1, b1, _, _ = P["fusion"][i + 1]["rcu1"]
+                self._lv[(b, i)] = (pyr, ops.conv(pyr, w1, b1, dtype, 256, ksize=3, relu=True))
+
+    def matches(self, B, S, H, W, dtype):
+        return self.key == (B, S, H, W, dtype)
+
+    def levels(self, b):
+        return {i: v for (bb, i), v in self._lv.items() if bb == b}
 
 
 class HipCameraHead:

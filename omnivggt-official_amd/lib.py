@@ -16,7 +16,7 @@ OVG_MAX_SEG = 8
 KV_TILE = 64
 ABI_VERSION = 11
 TILE_AUTO, TILE_128, TILE_256 = 0, 1, 2
-ATTN_F32X_EXACT_PV = 93                                        # ovg_attn_params.variant in the split-f16 mode: all three products of the PV contraction (default since round 6: two)
+ATTN_F32X_FAST_PV = 92                                         # ovg_attn_params.variant in the split-f16 mode (opt-in): PV without P_lo x V_hi, +16 % at 3e-5 .. 1e-4 instead of 1e-5 .. 5e-5
 TILE_R02_EPILOGUE, TILE_128X, TILE_256X = 16, 17, 18      # A/B flag (r02 epilogue forms) OR-ed onto a tile selector
 
 ERRORS = {0: "OVG_OK", -1: "OVG_E_ARG", -2: "OVG_E_DTYPE", -3: "OVG_E_LAUNCH", -4: "OVG_E_UNSUPPORTED"}

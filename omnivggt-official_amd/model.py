@@ -45,6 +45,9 @@ class OmniVGGT(nn.Module, _HubMixin):
         # caller's stream), so the camera head's ~250 tiny launches and the level-3 / level-4 convolutions of the two DPT heads (46-184 workgroups
         # on 256 CUs) overlap instead of queueing behind each other. Results are bit-identical to the sequential order.
         self.concurrent_heads = concurrent_heads
+        # round 6: the DPT pyramid levels that read aggregator layers 4 / 11 / 17 start as soon as that layer is done, on the heads' side streams,
+        # in the shadow of the remaining aggregator blocks (heads_hip.EarlyLevels); results are bit-identical to the late order
+        self.early_dpt_levels = True
         # frames per pass of the HIP DPT heads. The reference walks the views in chunks of 8 (dpt_head.py:133,163) to bound activation memory on
         # 24-80 GB parts; per-frame results do not depend on the chunking, the 288 GB of an MI355X hold 64 frames of head activations (~17 GB in
         # bf16), and the level-3 / level-4 convolutions (19^2 and 37^2 pixels per frame) only fill the chip from a few dozen frames on
@@ -69,30 +72,38 @@ class OmniVGGT(nn.Module, _HubMixin):
         self._hip_dpt = {"point": HipDPTHead(self.point_head), "depth": HipDPTHead(self.depth_head)}
         self._hip_cam = HipCameraHead(self.camera_head)
 
+    @staticmethod
+    def _head_streams(dev):
+        key = str(dev)
+        if key not in _HEAD_STREAMS:                   # created once per device, shared by all models of the process (not model state: nothing to copy / pickle)
+            _HEAD_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(3)]
+        return _HEAD_STREAMS[key]
+
     def _run_heads(self, jobs, concurrent):
-        """Run the head closures; concurrently = each on its own side stream between a fork event and a join on the caller's stream."""
+        """Run the head closures; concurrently = each on its own side stream between a fork event and a join on the caller's stream.
+        Job k runs on side stream k (camera, depth, point): the early pyramid levels of a DPT head (forward) were queued on the same stream."""
         if not concurrent or len(jobs) < 2:
             return {name: fn() for name, fn in jobs}
         cur = torch.cuda.current_stream()
         dev = cur.device
-        key = str(dev)
-        if key not in _HEAD_STREAMS:                   # created once per device, shared by all models of the process (not model state: nothing to copy / pickle)
-            _HEAD_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(3)]
-        streams = _HEAD_STREAMS[key]
+        streams = self._head_streams(dev)
         fork = torch.cuda.Event()
         fork.record(cur)
         res = {}
-        for (name, fn), st in zip(jobs, streams):
+        for name, fn in jobs:
+            st = streams[self._STREAM_OF[name]]
             st.wait_event(fork)
             with torch.cuda.stream(st):
                 res[name] = fn()
-        for _, st in zip(jobs, streams):
-            cur.wait_stream(st)
+        for name, _ in jobs:
+            cur.wait_stream(streams[self._STREAM_OF[name]])
         for val in res.values():                       # the outputs were allocated on a side stream and live on on the caller's
             for t in val:
                 if torch.is_tensor(t):
                     t.record_stream(cur)
         return res
+
+    _STREAM_OF = {"camera": 0, "depth": 1, "point": 2}
 
     def _camera(self, cam_tokens):
         dt = self.head_dtype or L.head_dtype(self.aggregator.compute_dtype)      # split-f16 aggregator: the heads run on the exact-f32 kernels
@@ -120,11 +131,46 @@ class OmniVGGT(nn.Module, _HubMixin):
             cap //= 2
         return max(cap, 8)
 
-    def _dpt(self, which, head, tokens, imgs32, patch_start_idx, concurrent=False):
+    def _dpt(self, which, head, tokens, imgs32, patch_start_idx, concurrent=False, early=None):
         dt = self.head_dtype or L.head_dtype(self.aggregator.compute_dtype)
         if self.hip_heads and imgs32.is_cuda and (dt in (torch.bfloat16, torch.float16) or self.hip_heads_f32):
-            return self._hip_dpt[which](tokens, imgs32, patch_start_idx, frames_chunk_size=self._frames_per_pass(imgs32, dt, concurrent), dtype=dt)   # f32: exact-f32 MFMA convolutions (r03)
+            return self._hip_dpt[which](tokens, imgs32, patch_start_idx, frames_chunk_size=self._frames_per_pass(imgs32, dt, concurrent), dtype=dt,
+                                        early=early)   # f32: exact-f32 MFMA convolutions (r03)
         return head(tokens, images=imgs32, patch_start_idx=patch_start_idx)
+
+    def _begin_early_levels(self, images):
+        """Round 6: while the aggregator still runs blocks 5 .. 23, the pyramid levels of the two DPT heads that read layers 4 / 11 / 17 are
+        computed on the heads' side streams (heads_hip.EarlyLevels) -- a per-layer hook of the aggregator waits for the layer on the side
+        stream and queues the level there. Only where the heads run concurrently on the HIP kernels and one pass covers all frames.
+        Returns ({head name: EarlyLevels}, hook) or ({}, None)."""
+        agg = self.aggregator
+        dt = self.head_dtype or L.head_dtype(agg.compute_dtype)
+        B, S, _, H, W = images.shape
+        ok = (self.early_dpt_levels and self.concurrent_heads and self.hip_heads and images.is_cuda and agg.shard is None
+              and (dt in (torch.bfloat16, torch.float16) or self.hip_heads_f32) and H % 14 == 0 and W % 14 == 0)
+        if not ok or self._frames_per_pass(images, dt, True) < S:
+            return {}, None
+        early = {}
+        for name, head in (("depth", self.depth_head), ("point", self.point_head)):
+            if head is not None:
+                early[name] = self._hip_dpt[name].begin_early(B, S, H, W, agg.patch_start_idx, dt)
+        if not early or not any(e.wants(i) for e in early.values() for i in range(agg.depth)):
+            return {}, None
+        streams = self._head_streams(images.device)
+
+        def hook(layer_index, layer_tokens):
+            takers = [(n, e) for n, e in early.items() if e.wants(layer_index)]
+            if not takers:
+                return
+            cur = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            for name, e in takers:
+                st = streams[self._STREAM_OF[name]]
+                st.wait_event(ready)
+                with torch.cuda.stream(st), torch.no_grad(), torch.amp.autocast("cuda", enabled=False):
+                    e.feed(layer_index, layer_tokens)
+        return early, hook
 
     def set_compute_dtype(self, dtype):
         self.aggregator.set_compute_dtype(dtype)
@@ -195,8 +241,13 @@ class OmniVGGT(nn.Module, _HubMixin):
         if camera_gt_index and (extrinsics is None or intrinsics is None):
             raise ValueError("camera_gt_index given without extrinsics/intrinsics tensors")
 
-        tokens, patch_start_idx = self.aggregator(images=images, extrinsics=extrinsics, intrinsics=intrinsics, depth=depth,
-                                                  mask=mask, depth_gt_index=depth_gt_index, camera_gt_index=camera_gt_index)
+        early, hook = self._begin_early_levels(images)
+        self.aggregator.layer_hook = hook
+        try:
+            tokens, patch_start_idx = self.aggregator(images=images, extrinsics=extrinsics, intrinsics=intrinsics, depth=depth,
+                                                      mask=mask, depth_gt_index=depth_gt_index, camera_gt_index=camera_gt_index)
+        finally:
+            self.aggregator.layer_hook = None
         out = {}
         shard = self.aggregator.shard
         sharded = shard is not None and not shard.gather_output
@@ -215,9 +266,9 @@ class OmniVGGT(nn.Module, _HubMixin):
             if self.camera_head is not None:
                 jobs.append(("camera", lambda: self._camera(cam_tokens)))
             if self.depth_head is not None:
-                jobs.append(("depth", lambda: self._dpt("depth", self.depth_head, tokens, imgs32, patch_start_idx, conc)))
+                jobs.append(("depth", lambda: self._dpt("depth", self.depth_head, tokens, imgs32, patch_start_idx, conc, early.get("depth"))))
             if self.point_head is not None:
-                jobs.append(("point", lambda: self._dpt("point", self.point_head, tokens, imgs32, patch_start_idx, conc)))
+                jobs.append(("point", lambda: self._dpt("point", self.point_head, tokens, imgs32, patch_start_idx, conc, early.get("point"))))
             res = self._run_heads(jobs, concurrent=conc)
             if "camera" in res:
                 out["pose_enc"], out["pose_enc_list"] = res["camera"][-1], res["camera"]

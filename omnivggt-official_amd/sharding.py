@@ -196,8 +196,8 @@ class HipExecutor:
         """One flash-attention launch, timed with a HIP event pair when bench.py asked for it."""
         nk = sum(s[2] for s in segs)
         dt, variant = self.agg.compute_dtype, self.agg.attn_variant
-        if ops.L.is_split(dt) and variant == 0 and getattr(self.agg, "f32x_exact_pv", False):
-            variant = ops.L.ATTN_F32X_EXACT_PV
+        if ops.L.is_split(dt) and variant == 0 and getattr(self.agg, "f32x_fast_pv", False):
+            variant = ops.L.ATTN_F32X_FAST_PV
         splits = getattr(self.agg, "attn_kv_splits", 0)
         cus = self.cus                                               # CUs left to the attention plans beside RCCL's channels (ViewSharding sets it)
         split_ws = None

@@ -437,10 +437,10 @@ def test_f32x(quick):
             ops.set_vt(vtd.hi, vh.hi)
             ops.set_vt(vtd.lo, vh.lo)
             segs.append((kd, vtd, nk))
-        # both forms of the PV contraction: all three products (variant ATTN_F32X_EXACT_PV: the 1e-5 kernel of rounds 4-5) and the default since
-        # round 6 without P_lo x V_hi -- P is then one f16 value per key (2^-11 relative), so on these adversarially peaky random logits
-        # (sigma ~ 10: a handful of keys carry a row) a row can be off by a few 1e-4 of the tensor maximum; the log-sum-exp is exact in both
-        for form, variant, ftol in (("", L.ATTN_F32X_EXACT_PV, tol), ("_pv2", 0, 4e-4)):
+        # both forms of the PV contraction: all three products (the mode: 1e-5) and the opt-in form without P_lo x V_hi (variant
+        # ATTN_F32X_FAST_PV) -- P is then one f16 value per key (2^-11 relative), so on these adversarially peaky random logits (sigma ~ 10:
+        # a handful of keys carry a row) a row can be off by a few 1e-4 of the tensor maximum; the log-sum-exp is exact in both
+        for form, variant, ftol in (("", 0, tol), ("_pv2", L.ATTN_F32X_FAST_PV, 4e-4)):
             lse = torch.zeros(BH, qd.shape[1], device=DEV) if want_lse else None
             out = ops.flash_attn(qd, segs, nq, dt, lse=lse, variant=variant)
             report("f32x_attn_" + tag + form, d64(out.hi.cpu()) + d64(out.lo.cpu()), ref_tok, ftol)
@@ -471,7 +471,7 @@ def test_f32x(quick):
         ops.set_vt(vtd.lo, vh.lo)
         rows = torch.tensor([0, 1, 255, 256, 257, 4095, 5000, n - 257, n - 2, n - 1])
         ref = attn_reference(d64(q32[:, rows]), d64(k32), d64(v32)).permute(1, 0, 2).reshape(len(rows), 1024)
-        for form, variant, ftol in (("", L.ATTN_F32X_EXACT_PV, TOLX), ("_pv2", 0, 4e-4)):
+        for form, variant, ftol in (("", 0, TOLX), ("_pv2", L.ATTN_F32X_FAST_PV, 4e-4)):
             out = ops.flash_attn(qd, [(kd, vtd, n)], n, dt, variant=variant)
             report("f32x_attn_global_n10992_rows" + form, (d64(out.hi[rows.to(DEV)].cpu()) + d64(out.lo[rows.to(DEV)].cpu())), ref, ftol)
 

@@ -674,3 +674,30 @@ def test_forced_split_kv_on_the_single_gpu_path():
     with pytest.raises(L.OvgError):
         ops.flash_attn(q, [(k, vt, n)], n, torch.bfloat16, kv_splits=4, split_ws=(part, lse[: lse.numel() // 2]))
     torch.cuda.synchronize()
+
+
+def test_early_dpt_levels_are_bit_identical_to_the_late_order():
+    """Round 6: OmniVGGT.forward starts the DPT pyramid levels that read aggregator layers 4 / 11 / 17 from a per-layer hook, on the heads' side
+    streams, while the aggregator is still running (heads_hip.EarlyLevels). Same kernels, same inputs, same order per level: every prediction
+    must be bit-identical to the forward that runs the whole head behind the last block -- in the bf16 mode (16-bit heads), in the split-f16
+    mode (exact-f32 heads), for a batch of two scenes, and with the hook left uninstalled afterwards."""
+    sd = common.full_state_dict()
+    m = build(sd, 24, 24, torch.bfloat16)
+    keys = ("pose_enc", "depth", "depth_conf", "world_points", "world_points_conf")
+    for dtype in (torch.bfloat16, L.F32X):
+        m.set_compute_dtype(dtype)
+        for B, S, dgi, cgi in ((1, 3, [1], [0, 2]), (2, 2, [], [0])):
+            parts = [orc.synthetic_inputs(S, seed=77 + b) for b in range(B)]
+            inp = {k: torch.cat([q[k] for q in parts], 0).to(DEV) for k in parts[0]}
+            outs = {}
+            for early in (True, False):
+                m.early_dpt_levels = early
+                with torch.no_grad():
+                    outs[early] = m(inp["images"], inp["extrinsics"], inp["intrinsics"], inp["depth"], inp["mask"], dgi, cgi)
+                torch.cuda.synchronize()
+                assert m.aggregator.layer_hook is None
+            for k in keys:
+                assert torch.equal(outs[True][k], outs[False][k]), (dtype, B, S, k)
+            del outs
+            torch.cuda.empty_cache()
+    m.early_dpt_levels = True

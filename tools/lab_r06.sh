@@ -31,6 +31,7 @@ for stage in "$@"; do
     selftest)    (timeout 1500 python tests/gpu_selftest.py --only ${OVG_SELFTEST_ONLY:-heads,f32x} 2>&1 | grep -v amdgpu.ids | tail -400) > "$O/selftest_${OVG_SELFTEST_TAG:-x}.log"; grep -E "FAIL|SELFTEST|Error|error" "$O/selftest_${OVG_SELFTEST_TAG:-x}.log" | head -20 ;;
     gemm_rotate) # 128^2 vs 256^2 at 8 views with the weights resident (the usual microbench) and streamed from HBM (48 copies in turn: the in-situ condition)
       for rot in 1 48; do echo "--- rotate $rot"; timeout 900 python tests/bench_kernels.py gemm --views ${OVG_AB_VIEWS:-8} --tiles 1 2 --rotate $rot --rounds 5 2>&1 | grep -v amdgpu.ids; done | tee "$O/gemm_rotate_ab.txt" ;;
+    rank_probe)  (for cfg in "8 2 8" "4 4 16" "2 4 32"; do echo "--- ranks / heads per launch / views per rank: $cfg"; timeout 600 python tools/probes/attn_rank_shape_probe.py $cfg 2>&1 | grep -v amdgpu.ids | tail -10; done) | tee "$O/attention_rank_shapes.txt" ;;
     *) echo "unknown stage $stage" ;;
   esac
 done

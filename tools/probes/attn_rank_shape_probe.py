@@ -18,7 +18,7 @@ for r in range(W):
 flop = 4.0 * W * gs * n * (W * n) * 64
 out = torch.empty(W * gs, q.shape[1], 64, device=DEV, dtype=dt)
 ref = None
-for variant, sp in ((50, 1), (0, 0), (50, 2), (50, 4), (50, 8), (57, 1), (71, 1)):
+for variant, sp in ((50, 1), (0, 0), (50, 4), (57, 1), (57, 3), (57, 4), (57, 5), (57, 6), (57, 8)):
     plan = ops.attn_plan(W * gs, n, [n] * W, dt, variant, sp, nq_pad=q.shape[1])
     ws = ops.alloc_split_ws(plan, DEV) if plan["splits"] > 1 else None
     f = lambda: ops.flash_attn(q, segs, n, dt, out=out, variant=variant, kv_heads=gs, head_major=True, kv_splits=sp, split_ws=ws)
