@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-4 GPU passes, one script with selectable stages (run through gpurun; everything lands under gpurun_out/r04/):
-#   tools/validate_r04.sh [tests] [attn_tests] [bench] [multirank] [traffic] [prof64] [prof8] [f32x] ...
+# Round-6 GPU passes, one script with selectable stages (run through gpurun; everything lands under gpurun_out/r05/):
+#   tools/validate_r06.sh [tests] [attn_tests] [bench] [multirank] [traffic] [prof64] [prof8] [f32x] ...
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r04
+O=$R/gpurun_out/r06v
 mkdir -p "$O"
 cd "$R"
 for stage in "$@"; do
@@ -33,8 +33,9 @@ for stage in "$@"; do
           rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$P/attn_S${v}_pmc$i" -- python "$R/tests/bench_kernels.py" attn --modes global --views $v --variants 0 --rounds 1 --target-ms 60 > "$P/last.log" 2>&1 || { echo "pass FAILED"; tail -5 "$P/last.log"; }
         done; done)
       python tools/traffic_json.py --views 8 "$P"/attn_S8_pmc3 "$P"/attn_S8_pmc4 --views 64 "$P"/attn_S64_pmc3 "$P"/attn_S64_pmc4 --out "$O/traffic.json" \
-        --source "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum / WRITE_SIZE TCC_MISS_sum passes (tools/validate_r04.sh traffic_only) of the shipped global-attention launches; PMC counters cannot be read from inside bench.py, so the figure is not re-measured in the bench run" > "$O/traffic_json.log" 2>&1
+        --source "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum / WRITE_SIZE TCC_MISS_sum passes (tools/validate_r06.sh traffic_only) of the shipped global-attention launches; PMC counters cannot be read from inside bench.py, so the figure is not re-measured in the bench run" > "$O/traffic_json.log" 2>&1
       python -c "import json; d=json.load(open('$O/traffic.json')); print('traffic', d['attention_source_digest'][:12], d['global_attn_S64_bytes_per_launch'], d['global_attn_S8_bytes_per_launch'])"
+      cp "$O/traffic.json" "$R/profiles/traffic.json"       # the bench stage of the same pass reads the record taken on THIS tree
       find "$P" -name "*.csv" -size +1M -delete ;;
     attn_ab)    (timeout 900 python tools/probes/attn_ab_probe.py ${OVG_AB_ARGS:-} 2>&1 | grep -v amdgpu.ids | tail -30) | tee "$O/attn_ab.txt" ;;
     configs)    # the other BASELINE configs + end-to-end lines (aggregator + three heads), one JSON line each
@@ -76,6 +77,48 @@ for stage in "$@"; do
     sweep)      for v in 4 12 16 24 32 48; do
         timeout 600 python bench.py --views $v --steps 6 --warmup 2 --no-cpu-baseline --no-parity 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('views', d['config']['views'], 'frames/s', d['value'], 'ms', d['ms_per_step'], 'attention ms', d['roofline']['avg_launch_ms'], 'frac', d['roofline']['frac'], 'fallback', d['roofline']['fallback_workgroups'])"
       done 2>&1 | tee "$O/bench_view_sweep.txt" ;;
+    attn_st)    (timeout 900 python tests/gpu_selftest.py --only attn,attn_big,lse_merge,fallback 2>&1 | grep -v amdgpu.ids | grep -E "FAIL|SELFTEST|Error|error|Traceback|raise|fault|core|keytail|\(attn" | head -80) | tee "$O/attn_selftest.txt" ;;
+    attn_ab8)   (timeout 900 python tests/bench_kernels.py attn --modes global --views ${OVG_AB_VIEWS:-8 9 10 12 13} --variants ${OVG_AB_VARIANTS:-0 50} --kv-splits ${OVG_AB_SPLITS:-0 1} --rounds 4 --target-ms 30 2>&1 | grep -v amdgpu.ids | tail -40) | tee "$O/attn_keytail_ab.txt" ;;
+    ckpt)       (timeout 1500 python tools/validate_checkpoint.py --synthetic /tmp/ovg_synth_ckpt.safetensors --views 2 8 --aux --out "$O/checkpoint_rehearsal.json" 2>&1 | grep -v amdgpu.ids | tail -60) | tee "$O/checkpoint_rehearsal.txt"; rm -f /tmp/ovg_synth_ckpt.safetensors ;;
+    heads_st)   (timeout 900 python tests/gpu_selftest.py --only heads 2>&1 | grep -v amdgpu.ids | grep -E "FAIL|SELFTEST|Error|error|Traceback|raise|fault|core|c256|dpt_tail|dpt_head|\(heads" | head -90) | tee "$O/heads_selftest.txt" ;;
+    e2e)        for v in 8 64; do timeout 900 python bench.py --views $v --steps 4 --warmup 1 --no-cpu-baseline --no-parity --no-secondary 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('views', d['config']['views'], 'aggregator frames/s', d['value'], 'e2e', d.get('e2e'), d.get('e2e_error'))"; done 2>&1 | tee "$O/bench_e2e.txt" ;;
+    prof_e2e8|prof_e2e64)
+      ev=${stage#prof_e2e}
+      (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_e2e_S$ev" -- python "$R/bench.py" --views $ev --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-secondary > "$O/prof_e2e_S$ev.log" 2>&1)
+      f=$(find "$O/prof_e2e_S$ev" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$O/bench_e2e_S${ev}_kernel_stats.csv" && head -16 "$f" | cut -c1-200
+      t=$(find "$O/prof_e2e_S$ev" -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python - "$t" <<'PY' | tee "$O/conv_launches_S$ev.txt"
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+agg = collections.defaultdict(list)
+for r in rows:
+    n = r["Kernel_Name"]
+    if "conv" in n or "upsample" in n or "dpt_out" in n or "dpt_tail" in n or "head_layernorm" in n:
+        agg[(n.split("(")[0][-60:], r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", ""))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+tot = sum(sum(v) for v in agg.values())
+for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+    print("%-62s grid %-9s calls %3d  avg %9.1f us  total %9.1f us  %5.1f %%" % (k[0], k[1], len(v), sum(v) / len(v), sum(v), 100 * sum(v) / tot))
+PY
+      find "$O/prof_e2e_S$ev" -name "*.csv" -size +1M -delete ;;
+    pmc_lite)   # SQ / GRBM counter passes on the shipped bf16 attention and GEMM launches (own runs, only --kernel-trace next to --pmc)
+      P=$O/prof_pmc; mkdir -p "$P"
+      (cd /tmp && export TMPDIR=/tmp
+       run() { "$@" > "$P/last.log" 2>&1 || { echo "   FAILED: $*"; tail -4 "$P/last.log"; }; }
+       i=0
+       for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+                  "SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE"; do
+         i=$((i + 1))
+         for v in 8 64; do
+           run rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$P/attn_S${v}_pmc$i" -- python "$R/tests/bench_kernels.py" attn --modes global --views $v --variants 0 --rounds 1 --target-ms 60
+           run rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$P/gemm_S${v}_pmc$i" -- python "$R/tests/bench_kernels.py" gemm --views $v --tiles 0 --rounds 1 --target-ms 5
+         done
+       done)
+      python tools/pmc_summary.py "$P"/attn_S* > "$O/pmc_attention.txt" 2>&1
+      python tools/pmc_summary.py "$P"/gemm_S64_* > "$O/pmc_gemm.txt" 2>&1
+      python tools/pmc_summary.py "$P"/gemm_S8_* > "$O/pmc_gemm_S8.txt" 2>&1
+      grep -h "grid=\|matrix pipe\|effective clock" "$O/pmc_attention.txt" "$O/pmc_gemm_S8.txt" | cut -c1-170 | head -40
+      find "$P" -name "*.csv" -size +1M -delete ;;
+    gemm_tl)    (timeout 900 python tools/probes/gemm_timeline.py ${OVG_TL_ARGS:-} 2>&1 | grep -v amdgpu.ids | tail -80) | tee "$O/gemm_timeline.txt" ;;
+    gemm_ab)    (timeout 900 python tests/bench_kernels.py gemm ${OVG_GEMM_AB_ARGS:---views 8 16 64 --tiles 1 2 --rounds 3} 2>&1 | grep -v amdgpu.ids | tail -80) | tee "$O/gemm_ab.txt" ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
