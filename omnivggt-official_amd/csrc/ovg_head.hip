@@ -383,6 +383,8 @@ extern "C" int ovg_conv(const ovg_conv_params* p, void* stream) {
   const int gemm_cols = s * s * p->Cout;
   if (p->dtype != OVG_F32 && !p->out_f32 && p->w_rows == gemm_cols && gemm_cols % 128 == 0 && p->Cin % 32 == 0 && (p->ksize * p->ksize * (p->Cin / 32)) % 2 == 0 &&
       M >= 16384 && two_images < ((int64_t)1 << 32) - 65536 && (int64_t)p->w_rows * p->ksize * p->ksize * p->Cin * 2 < ((int64_t)1 << 32)) {
+    // (round 6 lab, profiles/r06_heads_conv_choice_e2e_ab.txt: taking the 37^2 / 19^2 convolutions of short view counts on these kernels too -- from
+    // 2048 pixels, with 128-column tiles below 200 workgroups -- changes the 8-view end-to-end time by < 0.5 %, inside the run-to-run spread)
     const bool wide = gemm_cols % 256 == 0;
     const int nt2 = p->w_rows / (wide ? 256 : 128);
     const dim3 grid2((unsigned)(((M + 255) / 256) * nt2));

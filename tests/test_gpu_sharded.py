@@ -19,6 +19,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+import aggregator_oracle as orc
 import common
 from omnivggt_official_amd import lib as L, sharding
 from omnivggt_official_amd.model import OmniVGGT
@@ -82,6 +83,28 @@ def test_world_size_one_rccl_matches_unsharded():
             m.aggregator(*args)
         sh.skip_comm = False
         torch.cuda.synchronize()
+        # round 6: (B, S, ...) batches on the sharded path -- every batch entry's view axis is sharded like a B = 1 call (here: one rank, both
+        # exchange forms) -- against the unsharded forward of the same (2, S, ...) tensors, aggregator tokens and full-model predictions
+        parts2 = [orc.synthetic_inputs(S, seed=4321 + 999 * b) for b in range(2)]
+        args2 = tuple(torch.cat([q[k] for q in parts2], 0).to(DEV) for k in ("images", "extrinsics", "intrinsics", "depth", "mask")) + (dgi, cgi)
+        for mode in ("allgather", "heads"):
+            m.aggregator.shard = None
+            with torch.no_grad():
+                refb, _ = m.aggregator(*args2)
+                refb_out = m(*args2)
+            m.aggregator.shard = sharding.ViewSharding(gather_output=False, mode=mode)
+            with torch.no_grad():
+                gotb, _ = m.aggregator(*args2)
+                outb = m(*args2)
+            for a, b in zip(gotb, refb):
+                assert a.shape == b.shape == (2, S, 1374, 2048) and common.max_rel(a.cpu(), b.cpu()) <= 1e-6
+            for key in ("pose_enc", "depth", "world_points"):
+                assert outb[key].shape == refb_out[key].shape and common.max_rel(outb[key].cpu(), refb_out[key].cpu()) <= 1e-5
+        # round 6: bench.py's first-run insurance -- the rank's attention launch planned for several CU budgets, alone and beside an exchange
+        sh = m.aggregator.shard
+        table = sh.attention_cus_probe(m.aggregator, S, torch.device(DEV), [256, 224, 192], reps=2)
+        assert sorted(table) == [192, 224, 256] and all(v["alone_ms"] > 0 and v["under_exchange_ms"] > 0 for v in table.values()), table
+        assert sh.executor(m.aggregator, torch.device(DEV)).cus == 0 or sh.world > 1      # the probe restored the budget (one rank: whole device)
         # an explicit head-parallel request in the f32 parity mode is refused before any collective
         m.aggregator.set_compute_dtype(torch.float32)
         with pytest.raises(ValueError):

@@ -32,6 +32,12 @@ for stage in "$@"; do
     gemm_rotate) # 128^2 vs 256^2 at 8 views with the weights resident (the usual microbench) and streamed from HBM (48 copies in turn: the in-situ condition)
       for rot in 1 48; do echo "--- rotate $rot"; timeout 900 python tests/bench_kernels.py gemm --views ${OVG_AB_VIEWS:-8} --tiles 1 2 --rotate $rot --rounds 5 2>&1 | grep -v amdgpu.ids; done | tee "$O/gemm_rotate_ab.txt" ;;
     rank_probe)  (for cfg in "8 2 8" "4 4 16" "2 4 32"; do echo "--- ranks / heads per launch / views per rank: $cfg"; timeout 600 python tools/probes/attn_rank_shape_probe.py $cfg 2>&1 | grep -v amdgpu.ids | tail -10; done) | tee "$O/attention_rank_shapes.txt" ;;
+    insitu_e2e)  # end-to-end (aggregator + three heads) A/B of alternate builds: OVG_INSITU_LIBS="product cvA" OVG_INSITU_VIEWS="8 64"
+      for v in ${OVG_INSITU_VIEWS:-8}; do for rep in $(seq 1 ${OVG_INSITU_REPS:-2}); do for lib in ${OVG_INSITU_LIBS:-product cvA}; do
+        steps=$([ "$v" -ge 32 ] && echo 4 || echo 12)
+        timeout 600 python tools/probes/run_with_lib.py $lib bench.py --views $v --steps $steps --warmup 2 --no-cpu-baseline --no-parity --no-secondary 2>"$O/insitu.err" | tail -1 \
+          | python -c "import sys,json; d=json.loads(sys.stdin.read()); e=d.get('e2e',{}); print('e2e views $v lib $lib rep $rep: aggregator %.2f frames/s | e2e %.2f frames/s  %.3f ms/forward' % (d['value'], e.get('frames_per_s', 0), e.get('ms_per_forward', 0)))" || tail -5 "$O/insitu.err"
+      done; done; done 2>&1 | tee -a "$O/insitu_e2e_ab.txt" ;;
     *) echo "unknown stage $stage" ;;
   esac
 done

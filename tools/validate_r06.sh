@@ -30,7 +30,7 @@ for stage in "$@"; do
     traffic_only)
       P=$O/prof_traffic; mkdir -p "$P"
       (cd /tmp && export TMPDIR=/tmp && i=2 && for set in "FETCH_SIZE TCC_HIT_sum" "WRITE_SIZE TCC_MISS_sum"; do i=$((i + 1)); for v in 8 64; do
-          rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$P/attn_S${v}_pmc$i" -- python "$R/tests/bench_kernels.py" attn --modes global --views $v --variants 0 --rounds 1 --target-ms 60 > "$P/last.log" 2>&1 || { echo "pass FAILED"; tail -5 "$P/last.log"; }
+          rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$P/attn_S${v}_pmc$i" -- python "$R/tests/bench_kernels.py" attn --modes global --views $v --variants 0 --kv-splits 0 --rounds 1 --target-ms 60 > "$P/last.log" 2>&1 || { echo "pass FAILED"; tail -5 "$P/last.log"; }
         done; done)
       python tools/traffic_json.py --views 8 "$P"/attn_S8_pmc3 "$P"/attn_S8_pmc4 --views 64 "$P"/attn_S64_pmc3 "$P"/attn_S64_pmc4 --out "$O/traffic.json" \
         --source "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum / WRITE_SIZE TCC_MISS_sum passes (tools/validate_r06.sh traffic_only) of the shipped global-attention launches; PMC counters cannot be read from inside bench.py, so the figure is not re-measured in the bench run" > "$O/traffic_json.log" 2>&1
@@ -59,7 +59,7 @@ for stage in "$@"; do
                   "SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE"; do
          i=$((i + 1))
          for v in 8 64; do
-           run rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$P/attn_S${v}_pmc$i" -- python "$R/tests/bench_kernels.py" attn --modes global --views $v --variants 0 --rounds 1 --target-ms 60
+           run rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$P/attn_S${v}_pmc$i" -- python "$R/tests/bench_kernels.py" attn --modes global --views $v --variants 0 --kv-splits 0 --rounds 1 --target-ms 60
            run rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$P/gemm_S${v}_pmc$i" -- python "$R/tests/bench_kernels.py" gemm --views $v --tiles 0 --rounds 1 --target-ms 5
            run rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$P/f32x_S${v}_pmc$i" -- python "$R/bench.py" --dtype f32x --views $v --steps 1 --warmup 1 --no-cpu-baseline --no-parity --no-secondary
          done
@@ -108,7 +108,7 @@ PY
                   "SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE"; do
          i=$((i + 1))
          for v in 8 64; do
-           run rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$P/attn_S${v}_pmc$i" -- python "$R/tests/bench_kernels.py" attn --modes global --views $v --variants 0 --rounds 1 --target-ms 60
+           run rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$P/attn_S${v}_pmc$i" -- python "$R/tests/bench_kernels.py" attn --modes global --views $v --variants 0 --kv-splits 0 --rounds 1 --target-ms 60
            run rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$P/gemm_S${v}_pmc$i" -- python "$R/tests/bench_kernels.py" gemm --views $v --tiles 0 --rounds 1 --target-ms 5
          done
        done)
