@@ -962,19 +962,44 @@ int launch_linear256(const ovg_linear_params& p, hipStream_t st, bool xp) {
 // (profiles/r03_gemm_mlp256_insitu.txt): fc1 / fc2 alone on 256 x 256 below the threshold -- isolated +8 / +17 % at M = 10 992 -- still
 // LOSES in situ (4 / 8 / 12 views: -6.5 / -4 / -2.5 %; the global attention behind them 0.445 -> 0.482 ms): the threshold stays.
 // Returns 1 = use 256^2, 0 = use 128^2, -1 = the caller forced a tile this shape / dtype cannot run.
-int choose_256(int tile_arg, bool sixteen_bit, int64_t M, int64_t N, int64_t K, bool light_epilogue_or_long_k) {
+// Short launches (round 6, profiles/r06_gemm_short_launch_tiles_insitu.txt). Below 20 000 rows the 128 x 128 kernels stay the default -- fc1 on
+// 256 x 256 tiles at 8 views is isolated +21 % and in the forward -4.8 % (the global attention behind it clocks 0.442 -> 0.480 ms) -- with two
+// exceptions where the 256 x 256 launch fits ONE round of the chip (tiles <= CUs):
+//   fc2 (residual epilogue, K >= 2048) from 8 000 rows: 6 / 8 / 10 / 11 views +3.0 / +0.75 / +5.1 / +4.5 % on the forward (a K = 4096 tile amortises its
+//       fixed cost, and at 9-11 views the 128 x 128 launch needs a second round of 3 x CUs slots for an eighth of one); 12 views (260 tiles: two
+//       rounds) -1.5 %, so not beyond one round;
+//   proj (residual epilogue, K = 1024) only where the 128 x 128 launch would spill into such a second round (tiles128 > 3 x CUs).
+// kind: 0 = other, 1 = fc1 (GELU), 2 = fc2 (RES, K >= 2048), 3 = proj (RES, K < 2048)
+#ifndef OVG_PROJ_256_ONE_ROUND
+#define OVG_PROJ_256_ONE_ROUND 1
+#endif
+int gemm_device_cus() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    return v;
+  }();
+  return n;
+}
+int choose_256(int tile_arg, bool sixteen_bit, int64_t M, int64_t N, int64_t K, bool light_epilogue_or_long_k, int kind = 0) {
   const int tile = tile_arg & ~OVG_TILE_R02_EPILOGUE;      // the A/B flag does not take part in the tile choice
   const bool legal = sixteen_bit && N % g256::BN2 == 0 && K % 64 == 0;
   if (tile == OVG_TILE_128) return 0;
   if (tile == OVG_TILE_256) return legal ? 1 : -1;
   if (tile != OVG_TILE_AUTO) return -1;
-  if (!legal || !light_epilogue_or_long_k || M < 20000) return 0;
-  return 1;
+  if (!legal) return 0;
+  if (M >= 20000) return light_epilogue_or_long_k ? 1 : 0;
+  const int64_t cus = gemm_device_cus();
+  const int64_t t256 = ((M + 255) / 256) * (N / 256), t128 = ((M + 127) / 128) * (N / 128);
+  if (kind == 2 && M >= 8000 && t256 <= cus) return 1;
+  if (OVG_PROJ_256_ONE_ROUND && kind == 3 && t256 <= cus && t128 > 3 * cus) return 1;
+  return 0;
 }
 
 template <typename T>
 int launch_linear(const ovg_linear_params& p, hipStream_t st) {
-  const int big = choose_256(p.tile, sizeof(T) == 2, p.M, p.N, p.K, p.epilogue != OVG_EPI_RES || p.K >= 2048);
+  const int big = choose_256(p.tile, sizeof(T) == 2, p.M, p.N, p.K, p.epilogue != OVG_EPI_RES || p.K >= 2048,
+                             p.epilogue == OVG_EPI_GELU ? 1 : (p.epilogue == OVG_EPI_RES ? (p.K >= 2048 ? 2 : 3) : 0));
   if (big < 0) return OVG_E_ARG;
   if constexpr (sizeof(T) == 2) {
     if (big) return launch_linear256<T>(p, st, (p.tile & OVG_TILE_R02_EPILOGUE) != 0);

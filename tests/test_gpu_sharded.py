@@ -87,19 +87,26 @@ def test_world_size_one_rccl_matches_unsharded():
         # exchange forms) -- against the unsharded forward of the same (2, S, ...) tensors, aggregator tokens and full-model predictions
         parts2 = [orc.synthetic_inputs(S, seed=4321 + 999 * b) for b in range(2)]
         args2 = tuple(torch.cat([q[k] for q in parts2], 0).to(DEV) for k in ("images", "extrinsics", "intrinsics", "depth", "mask")) + (dgi, cgi)
+        # (the reference of "same kernels, same order" is the unsharded forward of each entry ALONE: the batched unsharded forward launches other
+        # geometries -- 32 attention entries, 2 S x 1374 GEMM rows -- and differs from it at the bf16 rounding level, test_batch_of_two_scenes_depth2)
+        entry = lambda b: tuple(t[b:b + 1] for t in args2[:5]) + (dgi, cgi)
+        m.aggregator.shard = None
+        with torch.no_grad():
+            per = [m.aggregator(*entry(b))[0] for b in range(2)]
+            per_out = [m(*entry(b)) for b in range(2)]
+            batched, _ = m.aggregator(*args2)
+        refb = [torch.cat([per[0][i], per[1][i]], 0) for i in range(len(per[0]))]
         for mode in ("allgather", "heads"):
-            m.aggregator.shard = None
-            with torch.no_grad():
-                refb, _ = m.aggregator(*args2)
-                refb_out = m(*args2)
             m.aggregator.shard = sharding.ViewSharding(gather_output=False, mode=mode)
             with torch.no_grad():
                 gotb, _ = m.aggregator(*args2)
                 outb = m(*args2)
-            for a, b in zip(gotb, refb):
+            for a, b, c in zip(gotb, refb, batched):
                 assert a.shape == b.shape == (2, S, 1374, 2048) and common.max_rel(a.cpu(), b.cpu()) <= 1e-6
+                assert common.max_rel(a.cpu(), c.cpu()) <= 3e-2                      # vs the batched unsharded launches: bf16 rounding level
             for key in ("pose_enc", "depth", "world_points"):
-                assert outb[key].shape == refb_out[key].shape and common.max_rel(outb[key].cpu(), refb_out[key].cpu()) <= 1e-5
+                refk = torch.cat([per_out[0][key], per_out[1][key]], 0)
+                assert outb[key].shape == refk.shape and common.max_rel(outb[key].cpu(), refk.cpu()) <= 1e-5
         # round 6: bench.py's first-run insurance -- the rank's attention launch planned for several CU budgets, alone and beside an exchange
         sh = m.aggregator.shard
         table = sh.attention_cus_probe(m.aggregator, S, torch.device(DEV), [256, 224, 192], reps=2)
