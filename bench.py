@@ -514,7 +514,8 @@ def main():
                 torch_heads = args.torch_heads or (hd == "f32" and not model.hip_heads_f32)
                 return {"views": Se, "frames_per_s": round(Se / ms * 1e3, 3), "ms_per_forward": round(ms, 3), "forwards_timed": reps,
                         "dpt_heads": "pytorch-f32" if torch_heads else "hip-" + hd, "camera_head": "pytorch-f32" if torch_heads else "hip-" + hd,
-                        "heads": "three side streams, %d frames per DPT pass, one-launch output stage" % model.dpt_frames_chunk if not torch_heads else "sequential"}
+                        "heads": ("three side streams, <= %d frames per DPT pass, one-launch output stage, pyramid levels of layers 4 / 11 / 17 started under the aggregator"
+                                  % model.dpt_frames_chunk) if not torch_heads else "sequential"}
             try:
                 wd.stage("end-to-end forward (aggregator + three heads)")
                 Se = args.e2e_views or S

@@ -601,3 +601,29 @@ def test_dpt_tail_patch_swizzle_is_conflict_free_and_consistent():
                         addrs.append(a)
                     for s in range(0, 64, 8):
                         assert len({(a // 16) % 8 for a in addrs[s:s + 8]}) == 8, (mb, ky, kx, kc, s)
+
+
+def test_dpt_pass_size_follows_free_memory_and_early_levels_pick_their_layers(monkeypatch):
+    """Round 6 host logic of the façade: (i) `dpt_frames_chunk` is an upper bound -- the pass actually taken fits half of the free device memory
+    (round-5 advisor: 64 frames x two concurrent heads x ~0.28 GB per frame and head OOMs smaller parts), never below the reference's 8 frames;
+    (ii) heads_hip.EarlyLevels takes exactly the aggregator layers that feed pyramid levels 0-2 and never the layer that ends the aggregator
+    (reduced-depth models clamp several levels onto the last layer: nothing to start early)."""
+    from omnivggt_official_amd import heads_hip
+    from omnivggt_official_amd.model import OmniVGGT
+    with torch.device("meta"):
+        m = OmniVGGT(compute_dtype=torch.bfloat16)
+        small = OmniVGGT(depth=2, dino_depth=2, compute_dtype=torch.bfloat16)
+
+    class FakeImages:
+        is_cuda, device = True, "cuda:0"
+        shape = (1, 64, 3, 518, 518)
+    for free_gb, concurrent, dt, want in ((250, True, torch.bfloat16, 64), (30, True, torch.bfloat16, 16), (30, False, torch.bfloat16, 32),
+                                          (30, True, torch.float32, 8), (2, True, torch.bfloat16, 8)):
+        monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None, g=free_gb: (int(g * 1e9), int(288e9)))
+        assert m._frames_per_pass(FakeImages, dt, concurrent) == want, (free_gb, concurrent, dt)
+    m.dpt_frames_chunk = 8
+    assert m._frames_per_pass(FakeImages, torch.bfloat16, True) == 8
+    e = heads_hip.EarlyLevels(m._hip_dpt["depth"], 1, 8, 518, 518, 5, torch.bfloat16)
+    assert [i for i in range(24) if e.wants(i)] == [4, 11, 17] and e.matches(1, 8, 518, 518, torch.bfloat16) and not e.matches(1, 9, 518, 518, torch.bfloat16)
+    e2 = heads_hip.EarlyLevels(small._hip_dpt["depth"], 1, 2, 518, 518, 5, torch.bfloat16)
+    assert not any(e2.wants(i) for i in range(2))
