@@ -39,21 +39,6 @@ OVG_DEV void tl_mark(int slot) {
   if (slot == 0) { row[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4); row[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20); row[6] = clock64(); }
   if (slot == 3) row[7] = clock64();
 }
-OVG_DEV unsigned long long tl_now() { return wall_clock64(); }
-OVG_DEV void tl_begin_persistent() {
-  if ((threadIdx.x & 63) != 0 || g_tl_buf == nullptr) return;
-  const int wave = threadIdx.x >> 6, last = (blockDim.x >> 6) - 1;
-  if (wave != 0 && wave != last) return;
-  unsigned long long* row = g_tl_buf + (size_t)blockIdx.x * 16 + (wave == 0 ? 0 : 8);
-  row[0] = wall_clock64(); row[4] = 0; row[5] = 0; row[6] = 0;
-}
-OVG_DEV void tl_piece(unsigned long long t_begin, unsigned long long t_loop, unsigned long long t_end) {   // persistent kernels: per-workgroup sums over its pieces
-  if ((threadIdx.x & 63) != 0 || g_tl_buf == nullptr) return;
-  const int wave = threadIdx.x >> 6, last = (blockDim.x >> 6) - 1;
-  if (wave != 0 && wave != last) return;
-  unsigned long long* row = g_tl_buf + (size_t)blockIdx.x * 16 + (wave == 0 ? 0 : 8);
-  row[4] += 1; row[5] += t_loop - t_begin; row[6] += t_end - t_loop;
-}
 OVG_DEV void tl_stagger() {
   if (g_tl_stagger <= 0 || blockIdx.x >= 256) return;
   const unsigned long long until = wall_clock64() + (unsigned long long)(((blockIdx.x >> 3) & 7) * g_tl_stagger);
@@ -61,9 +46,6 @@ OVG_DEV void tl_stagger() {
 }
 #else
 OVG_DEV void tl_mark(int) {}
-OVG_DEV unsigned long long tl_now() { return 0; }
-OVG_DEV void tl_begin_persistent() {}
-OVG_DEV void tl_piece(unsigned long long, unsigned long long, unsigned long long) {}
 OVG_DEV void tl_stagger() {}
 #endif
 
@@ -252,7 +234,7 @@ OVG_DEV void gemm_mainloop(const T* __restrict__ X, int64_t ldx, const T* __rest
 // -- and, registers permitting, the next row block's -- are in flight together.
 template <typename T, int EPI, bool OUT_F32, int MT, bool INJECT, int XP = 0, bool X3 = false>   // XP = 1 (OVG_TILE_R02_EPILOGUE, A/B flag): the r02 erf_as GELU instead of the polynomial one; X3: split-f16 outputs (hi / lo planes), libm erff
 OVG_DEV void linear_epilogue_impl(const ovg_linear_params& p, const f32x4 (&acc)[4][MT], const int m_w0, const int n_w0, const int row_lim = -1) {
-  const int M = row_lim >= 0 ? row_lim : (int)p.M, N = (int)p.N;   // row_lim: rows >= it belong to somebody else (persistent kernel: piece / wave-group end)
+  const int M = row_lim >= 0 ? row_lim : (int)p.M, N = (int)p.N;   // row_lim: rows >= it belong to somebody else (unused by the shipped kernels: -1)
   const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
   const int ncol = n_w0 + 4 * g;                       // this lane's first column of n-block 0; block nt adds 16 nt
   f32x4 bias[4], gam[4];

@@ -81,8 +81,6 @@ def main():
         for t in args.tiles:
             tb = 128 if t == 1 else 256
             nwg = ((M + tb - 1) // tb) * (N // tb)
-            if t == 4:
-                nwg = torch.cuda.get_device_properties(0).multi_processor_count       # persistent: one workgroup per CU (two launches for QKV: the stamps are the V^T launch's)
             L._lib = prod
             fn(t)
             ms_prod = statistics.median(timed(lambda: fn(t), 5) for _ in range(5))
@@ -98,18 +96,6 @@ def main():
                 torch.cuda.synchronize()
                 a = buf.cpu().numpy().reshape(nwg, 2, 8).astype(np.int64)
                 assert lab.ovg_lab_gemm_timeline(0, 0) == 0
-                if t == 4:
-                    live = a[:, 0, 0] > 0
-                    b0 = a[live]
-                    t0 = b0[:, :, 0].min()
-                    tot = (np.maximum(b0[:, 0, 3], b0[:, 1, 3]) - b0[:, 0, 0]) * TICK_US
-                    print("tl %-5s M=%-6d N=%-5d K=%-5d tile=4 persistent wgs=%d | product %.4f ms (%.0f TF) lab %.4f ms (%.0f TF) span %.1f us | per WG: pieces %.1f/%d loop sum %.1f/%.1f us epilogue sum "
-                          "(w0) %.1f/%.1f (wlast) %.1f/%.1f total %.1f/%.1f (median/p90 or max) | per piece: loop %.2f us epilogue %.2f / %.2f us"
-                          % (nm, M, N, K, int(live.sum()), ms_prod, flop / ms_prod / 1e9, ms, flop / ms / 1e9, (np.maximum(b0[:, 0, 3], b0[:, 1, 3]).max() - t0) * TICK_US,
-                             float(np.median(b0[:, 0, 4])), int(b0[:, 0, 4].max()), pct(b0[:, 0, 5] * TICK_US, 50), pct(b0[:, 0, 5] * TICK_US, 90),
-                             pct(b0[:, 0, 6] * TICK_US, 50), pct(b0[:, 0, 6] * TICK_US, 90), pct(b0[:, 1, 6] * TICK_US, 50), pct(b0[:, 1, 6] * TICK_US, 90), pct(tot, 50), pct(tot, 90),
-                             float(b0[:, 0, 5].sum() / b0[:, 0, 4].sum() * TICK_US), float(b0[:, 0, 6].sum() / b0[:, 0, 4].sum() * TICK_US), float(b0[:, 1, 6].sum() / b0[:, 1, 4].sum() * TICK_US)), flush=True)
-                    continue
                 t0 = a[:, :, 0].min()
                 w0, w1 = a[:, 0, :4] - t0, a[:, 1, :4] - t0            # first / last wave stamps, ticks from the first entry
                 span = max(w0[:, 3].max(), w1[:, 3].max()) * TICK_US
