@@ -47,7 +47,7 @@ for stage in "$@"; do
       run bench_f32x_e2e_S8 --dtype f32x --views 8 --steps 5 --warmup 1 --no-parity --e2e --e2e-views 8
       run bench_f32_S64 --dtype f32 --views 64 --steps 2 --warmup 1 --no-parity ;;
     printed)    (timeout 1500 python -m pytest tests/test_gpu_aggregator.py tests/test_gpu_sharded.py tests/test_gpu_kernels.py -m gpu -q -s \
-                   -k "full_depth_8_views or attention_sinks or eight_ranks_allgather or headline_64 or stress_128" 2>&1 | grep -E "vs oracle|re-ran|emulated ranks|passed|failed|Error" | cut -c1-400) | tee "$O/printed_parity_numbers.txt" ;;
+                   -k "full_depth_8_views or full_depth_16_views or batch_of_two_scenes_full or attention_sinks or eight_ranks_allgather or headline_64 or stress_128" 2>&1 | grep -E "vs oracle|re-ran|emulated ranks|passed|failed|Error" | cut -c1-400) | tee "$O/printed_parity_numbers.txt" ;;
     multirank_f32x) OVG_MULTIRANK_CFGS="2:8" OVG_MULTIRANK_ARGS="--dtype f32x --no-second-form" bash tools/multirank_one_gpu.sh 2>&1 | tee "$O/multirank_one_gpu_gloo_f32x.txt" ;;
     heads_dtype) (timeout 900 python tools/probes/heads_dtype_probe.py 2>&1 | grep -v amdgpu.ids | tail -20) | tee "$O/heads_dtype_probe.txt" ;;
     pmc)        # SQ / GRBM counter passes (own runs, only --kernel-trace next to --pmc): shipped bf16 attention and GEMM launches, split-f16 forward
