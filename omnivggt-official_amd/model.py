@@ -18,8 +18,6 @@ ovg_camera_head (16-bit weight streams; residual stream, statistics, softmax and
 `hip_heads=False` forces the PyTorch heads everywhere, `hip_camera_head=False` only the camera head (pose_enc then carries
 no 16-bit head error: 3.6 ms instead of 1.2 ms at 8 views).
 """
-import os
-
 import torch
 import torch.nn as nn
 
@@ -265,16 +263,13 @@ class OmniVGGT(nn.Module, _HubMixin):
                 imgs32 = imgs32[:, lo:hi]
             jobs = []
             conc = bool(self.concurrent_heads and self.hip_heads and not sharded and imgs32.is_cuda)
+            if self.camera_head is not None:
+                jobs.append(("camera", lambda: self._camera(cam_tokens)))
             if self.depth_head is not None:
                 jobs.append(("depth", lambda: self._dpt("depth", self.depth_head, tokens, imgs32, patch_start_idx, conc, early.get("depth"))))
             if self.point_head is not None:
                 jobs.append(("point", lambda: self._dpt("point", self.point_head, tokens, imgs32, patch_start_idx, conc, early.get("point"))))
-            if self.camera_head is not None:
-                jobs.append(("camera", lambda: self._camera(cam_tokens)))
-            if os.environ.get("OVG_HEADS_CAMERA_FIRST") == "1" or not conc:
-                # the reference's order (omnivggt.py:47-61); with side streams the two DPT heads are QUEUED first instead: the camera head's one C
-                # call issues ~165 tiny launches (~1 ms of host time at 8 views) during which nothing of the DPT heads would be enqueued yet
-                jobs = jobs[-1:] + jobs[:-1] if jobs and jobs[-1][0] == "camera" else jobs
+            # (queueing the two DPT heads in front of the camera head's ~165 tiny launches measured no difference: the host is far ahead of the device)
             res = self._run_heads(jobs, concurrent=conc)
             if "camera" in res:
                 out["pose_enc"], out["pose_enc_list"] = res["camera"][-1], res["camera"]
