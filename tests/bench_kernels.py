@@ -82,6 +82,8 @@ def gemm(args):
     for S in args.views:
         M = S * 1374
         shapes += [("qkv", M, 3072, 1024, "qkv"), ("proj", M, 1024, 1024, L.EPI_RES), ("fc1", M, 4096, 1024, L.EPI_GELU), ("fc2", M, 1024, 4096, L.EPI_RES)]
+    if args.no_qkv:
+        shapes = [sh for sh in shapes if sh[4] != "qkv"]
     for n in args.square:
         shapes.append(("sq%d" % n, n, n, n, L.EPI_STORE))
     for nm, M, N, K, epi in shapes:
@@ -152,6 +154,7 @@ def main():
     ap.add_argument("--square", type=int, nargs="*", default=[], help="GEMM: also time n^3 STORE problems (e.g. 4096 8192)")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--target-ms", type=float, default=20.0)
+    ap.add_argument("--no-qkv", action="store_true", help="GEMM: skip the QKV shape (lab tiles that exist for ovg_linear only)")
     ap.add_argument("--rotate", type=int, default=1, help="GEMM: cycle over this many copies of the weight matrix (weights from HBM, as in the forward)")
     ap.add_argument("--out", default="")
     ap.add_argument("--alt-lib", default="", help="name of an alternate build under tools/probes/_build/ (build_alt.py) to run on instead of the product library")
