@@ -38,7 +38,7 @@ for stage in "$@"; do
         timeout 600 python tools/probes/run_with_lib.py $lib bench.py --views $v --steps $steps --warmup 2 --no-cpu-baseline --no-parity --no-secondary 2>"$O/insitu.err" | tail -1 \
           | python -c "import sys,json; d=json.loads(sys.stdin.read()); e=d.get('e2e',{}); print('e2e views $v lib $lib rep $rep: aggregator %.2f frames/s | e2e %.2f frames/s  %.3f ms/forward' % (d['value'], e.get('frames_per_s', 0), e.get('ms_per_forward', 0)))" || tail -5 "$O/insitu.err"
       done; done; done 2>&1 | tee -a "$O/insitu_e2e_ab.txt" ;;
-    gemm128f_ab) (timeout 1200 python tests/bench_kernels.py gemm --alt-lib lab --no-qkv --views ${OVG_AB_VIEWS:-8 16} --square 4096 --tiles 1 33 2 --rounds 5 2>&1 | grep -v amdgpu.ids) | tee "$O/gemm128f_ab.txt" | tail -40 ;;
+    # (gemm128f_ab -- tile 33, the 128 x 128 free-running lab kernel -- ran from commit 'Review item 1c measured'; its kernel left the tree with that commit)
     *) echo "unknown stage $stage" ;;
   esac
 done
