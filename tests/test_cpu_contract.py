@@ -627,3 +627,22 @@ def test_dpt_pass_size_follows_free_memory_and_early_levels_pick_their_layers(mo
     assert [i for i in range(24) if e.wants(i)] == [4, 11, 17] and e.matches(1, 8, 518, 518, torch.bfloat16) and not e.matches(1, 9, 518, 518, torch.bfloat16)
     e2 = heads_hip.EarlyLevels(small._hip_dpt["depth"], 1, 2, 518, 518, 5, torch.bfloat16)
     assert not any(e2.wants(i) for i in range(2))
+
+
+def test_bench_parses_rccl_channel_lines(tmp_path, monkeypatch):
+    """Round-5 review item 7: bench.py at N > 1 points RCCL's INFO log of every rank at a file and reports the channel counts RCCL
+    actually set up (`comm.rccl_channels_observed`) -- what sharding.available_cus() should have subtracted. The parser against the line
+    formats of RCCL 2.2x; a job that configured NCCL_DEBUG itself, or a log without the lines, yields a reason instead of numbers."""
+    import bench
+    log = tmp_path / "rccl_rank3.log"
+    monkeypatch.setattr(bench, "RCCL_LOG", str(tmp_path / "rccl_rank%d.log"))
+    monkeypatch.setenv("NCCL_DEBUG_FILE", str(log))
+    log.write_text("runc:77:77 [3] NCCL INFO RCCL version 2.26.6-HEAD:64f48b6\n"
+                   "runc:77:102 [3] NCCL INFO Channel 00/32 : 0 1 2 3 4 5 6 7\n"
+                   "runc:77:102 [3] NCCL INFO 32 coll channels, 0 collnet channels, 0 nvls channels, 32 p2p channels, 2 p2p channels per peer\n"
+                   "runc:77:140 [3] NCCL INFO 16 coll channels, 0 collnet channels, 0 nvls channels, 16 p2p channels, 2 p2p channels per peer\n")
+    assert bench.rccl_channels_observed(3) == {"coll_channels": 32, "p2p_channels": 32, "p2p_channels_per_peer": 2, "version": "2.26.6-HEAD:64f48b6"}
+    log.write_text("nothing about channels here\n")
+    assert "unavailable" in bench.rccl_channels_observed(3)
+    monkeypatch.setenv("NCCL_DEBUG_FILE", "/somewhere/else.log")
+    assert "unavailable" in bench.rccl_channels_observed(3)
