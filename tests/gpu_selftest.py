@@ -532,6 +532,11 @@ def test_heads(quick):
         conv_case("c256_1x1_pos_2048to512", 12, 37, 37, 2048, 512, pos=True)
         conv_case("c256_convT2_512", 12, 37, 37, 512, 512, up=2)
         conv_case("c256_3x3s2_1024", 14, 74, 74, 1024, 1024, k=3, stride=2)
+        # round 6: the free-running loop's shortest k loops (2 k-stages: prologue + drain only) and the 128-column geometry (two workgroups per CU,
+        # 3-slot ring: 18 and 72 k-stages, border taps through the out-of-range DMA offsets)
+        conv_case("c256_1x1_64to256_two_stages", 1, 148, 148, 64, 256)
+        conv_case("c256n_3x3_64to128", 1, 148, 148, 64, 128, k=3, relu=True)
+        conv_case("c256n_3x3_256to128_two_images", 2, 131, 127, 256, 128, k=3, adds=1)
         # bilinear align_corners resize (+ UV tables)
         for tag, n, H, W, OH, OW, c, pos in (("19to37", 2, 19, 19, 37, 37, 256, False), ("37to74", 1, 37, 37, 74, 74, 256, False),
                                              ("148to296", 1, 148, 148, 296, 296, 256, False), ("296to518_pos", 1, 296, 296, 518, 518, 128, True)):
@@ -701,7 +706,8 @@ def test_gemm256(quick, tile=None, auto_is=True):
     T256 = L.TILE_256 if tile is None else tile
     for name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
         tol = TOL[name]
-        shapes = [(777, 1024, 1024), (33000, 4096, 1024), (33000, 1024, 4096)]
+        # (the short-K shapes walk the prologue / drain logic of the free-running loop: 2, 4 and 6 k-stages against a 4-slot ring)
+        shapes = [(777, 1024, 1024), (33000, 4096, 1024), (33000, 1024, 4096), (777, 256, 64), (1000, 512, 128), (520, 256, 192)]
         if not quick and name == "bf16":
             shapes.append((64 * 1374, 4096, 1024))        # the bench's own M: 344 x 16 = 5504 workgroups, XCD remap at full size
         for (M, N, K) in shapes:
